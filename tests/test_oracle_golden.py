@@ -1,0 +1,250 @@
+"""Pin the CPU oracle against the fixtures generated from the reference's Python twin
+(tests/golden/make_golden.py) and against algebraic invariants.
+
+Tolerances: discrete outputs (word lists, path counts, point counts, flags, rasters) exact;
+lengths/costs/trajectories 1e-9 relative (the twin's floored `%` vs the crate's truncated `%`
+and summation order differ at the 1e-11 level)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from path_planner_amd import _abi as A
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+CONF = A.demo_config()
+
+
+def load(name):
+    with open(os.path.join(G, name)) as f:
+        return json.load(f)
+
+
+def close(a, b, rel=1e-9, abs_=1e-9):
+    return abs(a - b) <= max(abs_, rel * max(abs(a), abs(b)))
+
+
+def check_paths(got, exp, full):
+    assert [p["ctypes"] for p in got] == [p["ctypes"] for p in exp]
+    for pg, pe in zip(got, exp):
+        assert np.allclose(pg["lengths"], pe["lengths"], rtol=1e-9, atol=1e-9)
+        assert close(pg["total"], pe["total"])
+        assert len(pg["x"]) == pe["npts"]
+        if full:
+            assert np.allclose(pg["x"], pe["x"], rtol=1e-9, atol=1e-9)
+            assert np.allclose(pg["y"], pe["y"], rtol=1e-9, atol=1e-9)
+            assert np.allclose(pg["yaw"], pe["yaw"], rtol=1e-9, atol=1e-9)
+            assert list(pg["dir"]) == pe["dir"]
+        else:
+            assert close(float(np.sum(pg["x"])), pe["sum_x"], 1e-9, 1e-7)
+            assert close(float(np.sum(pg["y"])), pe["sum_y"], 1e-9, 1e-7)
+            assert close(float(np.sum(pg["yaw"])), pe["sum_yaw"], 1e-9, 1e-7)
+            assert np.allclose([pg["x"][-1], pg["y"][-1], pg["yaw"][-1]], pe["last"], atol=1e-9)
+            assert int(np.sum(pg["dir"] > 0)) == pe["ndir_fwd"]
+
+
+def test_rs_demo_legs():
+    legs = load("rs_demo_legs.json")
+    assert [len(l["paths"]) for l in legs] == [5, 5, 6, 7, 6, 5, 5]
+    for leg in legs:
+        st, paths = O.rs_all_paths(leg["q0"], leg["q1"], leg["maxc"], leg["step"])
+        assert st == 0
+        check_paths(paths, leg["paths"], True)
+        s = np.array([leg["q0"]])
+        g = np.array([leg["q1"]])
+        st, npaths, best, words, flags = O.rs_batch(s, g, leg["maxc"])
+        assert npaths[0] == len(leg["paths"]) and best[0] == leg["best"]
+        assert words[0].word() == leg["paths"][leg["best"]]["ctypes"]
+
+
+def test_rs_random_pairs():
+    data = load("rs_random.json")
+    maxc, step = data["maxc"], data["step"]
+    hist = {}
+    for pr in data["pairs"]:
+        st, paths = O.rs_all_paths(pr["q0"], pr["q1"], maxc, step)
+        assert st == 0
+        check_paths(paths, pr["paths"], "x" in pr["paths"][0])
+        st, npaths, best, words, flags = O.rs_batch([pr["q0"]], [pr["q1"]], maxc)
+        assert best[0] == pr["best"]
+        for k, p in enumerate(paths):
+            w = A.RsWord()
+            for i, (l, c) in enumerate(zip(p["lengths"], p["ctypes"])):
+                w.lengths[i] = l
+                w.ctypes[i] = ord(c)
+            w.nseg = len(p["ctypes"])
+            assert close(O.rs_path_cost(w, CONF), pr["costs"][k])
+            hist[p["ctypes"]] = hist.get(p["ctypes"], 0) + 1
+    # every word family of the reference is exercised by the fixture
+    for fam in ["SLS", "SRS", "LSL", "RSR", "LSR", "RSL", "LRL", "RLR", "LRLR", "RLRL", "LRSL",
+                "RLSR", "LRSR", "RLSL", "LSRL", "RSLR", "RSRL", "LSLR", "LRSLR", "RLSRL"]:
+        assert hist.get(fam, 0) > 0, fam
+
+
+def test_rs_paths_end_at_goal():
+    rng = np.random.default_rng(7)
+    maxc = math.tan(0.6) / 3.5
+    for _ in range(200):
+        q0 = [rng.uniform(0, 50), rng.uniform(0, 50), rng.uniform(-math.pi, math.pi)]
+        q1 = [rng.uniform(0, 50), rng.uniform(0, 50), rng.uniform(-math.pi, math.pi)]
+        st, paths = O.rs_all_paths(q0, q1, maxc, 0.4)
+        assert st == 0 and len(paths) > 0
+        for p in paths:
+            assert abs(p["x"][-1] - q1[0]) < 1e-8 and abs(p["y"][-1] - q1[1]) < 1e-8
+            dyaw = (p["yaw"][-1] - q1[2] + math.pi) % (2 * math.pi) - math.pi
+            assert abs(dyaw) < 1e-8
+            assert p["x"][0] == q0[0] and p["y"][0] == q0[1]
+
+
+def test_rs_degenerate_pair_reports_assert():
+    n = A.C.c_int32(0)
+    words = (A.RsWord * A.PP_RS_MAX_PATHS)()
+    st = O.lib().orc_rs_words(1.0, 2.0, 0.3, 1.0, 2.0, 0.3, 0.2, A.C.byref(n), words)
+    # start == goal: every CSC family yields a zero-length word -> the :157 assert
+    assert st == A.PP_ERR_DEGENERATE_RS
+
+
+def test_collision_flags_golden():
+    col = load("collision.json")
+    from path_planner_amd import workloads as D
+    ox, oy = D.demo_obstacles()
+    m = O.OracleMap(ox, oy)
+    poses = np.array(col["demo"]["poses"])
+    for mode in (0, 1):
+        st, flags = m.collision_flags(CONF, poses[:, 0], poses[:, 1], poses[:, 2], mode)
+        assert st == 0
+        assert flags.tolist() == col["demo"]["flags"]
+    sc = col["scatter"]
+    m2 = O.OracleMap(sc["ox"], sc["oy"])
+    poses = np.array(sc["poses"])
+    for mode in (0, 1):
+        st, flags = m2.collision_flags(CONF, poses[:, 0], poses[:, 1], poses[:, 2], mode)
+        assert flags.tolist() == sc["flags"]
+    st, flags = m2.collision_flags(CONF, poses[:, 0], poses[:, 1], poses[:, 2], threads=2)
+    assert flags.tolist() == sc["flags"]
+    assert 0.1 < np.mean(sc["flags"]) < 0.9
+
+
+def test_collision_invariant_under_obstacle_permutation_and_duplication():
+    rng = np.random.default_rng(3)
+    ox, oy = rng.uniform(0, 40, 300), rng.uniform(0, 40, 300)
+    x, y, yaw = rng.uniform(0, 40, 2000), rng.uniform(0, 40, 2000), rng.uniform(-7, 7, 2000)
+    _, f0 = O.OracleMap(ox, oy).collision_flags(CONF, x, y, yaw)
+    perm = rng.permutation(300)
+    ox2 = np.concatenate([ox[perm], ox[:50]])
+    oy2 = np.concatenate([oy[perm], oy[:50]])
+    _, f1 = O.OracleMap(ox2, oy2).collision_flags(CONF, x, y, yaw)
+    assert (f0 == f1).all()
+
+
+def test_obsmap_and_heuristic_golden():
+    from path_planner_amd import workloads as D
+    ox, oy = D.demo_obstacles()
+    for h in load("heuristic.json"):
+        hox, hoy = (h["ox"], h["oy"]) if "ox" in h else (ox, oy)
+        for mode in (0, 1):
+            st, obs, dims = O.obsmap(hox, hoy, h["reso"], h["rr"], mode)
+            assert st == 0 and dims.tolist() == h["dims"]
+            assert obs.tolist() == h["obsmap"]
+        st, hm, dims = O.heuristic(hox, hoy, h["gx"], h["gy"], h["reso"], h["rr"])
+        assert st == 0
+        exp = np.array([[math.inf if v == "inf" else v for v in row] for row in h["hmap"]])
+        assert hm.shape == exp.shape
+        assert (np.isinf(hm) == np.isinf(exp)).all()
+        fin = np.isfinite(exp)
+        # same additions of 1.0 and hypot(1,1) along some shortest path: bitwise equal
+        assert (hm[fin] == exp[fin]).all()
+
+
+def test_wavefront_is_relaxation_fixpoint():
+    rng = np.random.default_rng(11)
+    for trial in range(20):
+        xw, yw = int(rng.integers(8, 60)), int(rng.integers(8, 60))
+        obs = (rng.random((xw, yw)) < rng.uniform(0.1, 0.4)).astype(np.uint8)
+        gx, gy = int(rng.integers(1, xw - 1)), int(rng.integers(1, yw - 1))
+        st, cost = O.wavefront(obs, gx, gy)
+        assert st == 0 and cost[gx, gy] == 0.0
+        ref = D_fixpoint(obs, gx, gy)
+        assert (np.isinf(cost) == np.isinf(ref)).all()
+        fin = np.isfinite(ref)
+        assert (cost[fin] == ref[fin]).all()
+
+
+def D_fixpoint(obs, gx, gy):
+    """Order-free relaxation d[v] = min_n fl(d[n] + w) by Jacobi sweeps (numpy)."""
+    xw, yw = obs.shape
+    valid = np.zeros((xw, yw), bool)
+    valid[1:, 1:] = True  # check_node with minx=miny=0, maxx=xw, maxy=yw: 0 < x < xw, 0 < y < yw
+    valid &= obs == 0
+    d = np.full((xw, yw), np.inf)
+    d[gx, gy] = 0.0
+    s2 = math.hypot(1.0, 1.0)
+    while True:
+        p = np.pad(d, 1, constant_values=np.inf)
+        best = d.copy()
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                if dx == 0 and dy == 0:
+                    continue
+                w = 1.0 if dx == 0 or dy == 0 else s2
+                cand = p[1 + dx:1 + dx + xw, 1 + dy:1 + dy + yw] + w
+                cand = np.where(valid, cand, np.inf)
+                best = np.minimum(best, cand)
+        best[gx, gy] = 0.0
+        if (best == d).all():
+            return d
+        d = best
+
+
+def test_motion_set_and_rollout_costs():
+    steer, direc = O.motion_set(CONF)
+    assert len(steer) == 78 and (direc[:39] == 1).all() and (direc[39:] == -1).all()
+    assert steer[0] == 1.0 * 0.6 / 20.0 and steer[18] == 19.0 * 0.6 / 20.0 and steer[19] == 0.0
+    assert (steer[20:39] == -steer[:19]).all() and (steer[39:] == steer[:39]).all()
+    # rollout yaw is a pure recurrence in tan(u): closed-form check of the g-cost
+    from path_planner_amd import workloads as D
+    ox, oy = D.demo_obstacles()
+    m = O.OracleMap(ox, oy)
+    st, out = m.expand(CONF, [10.0], [7.0], [math.radians(120.0)], [1], [0.0], [0.0])
+    assert st == 0
+    for i in range(78):
+        if out["valid"][i]:
+            c = 4.0 if direc[i] > 0 else 4.0 * 5.0
+            if direc[i] < 0:
+                c += 100.0
+            c += 1.0 * abs(steer[i])
+            c += 5.0 * abs(0.0 - steer[i])
+            assert out["cost"][i] == c
+    assert 0 < out["valid"].sum() < 78
+
+
+def test_plan_demo_map_matches_provisional_rust_semantics():
+    """The demo query of src/main.rs:215-269.  Expected values were derived independently by
+    emulating the Rust semantics on the Python twin (rounding, heap order, un-wrapped yaw)."""
+    from path_planner_amd import workloads as D
+    ox, oy = D.demo_obstacles()
+    m = O.OracleMap(ox, oy)
+    P = m.param(CONF)
+    assert (P.minx, P.miny, P.minyaw, P.maxx, P.maxy, P.xw, P.yw) == (0, 0, -13, 25, 15, 25, 15)
+    st, hm, dims = O.heuristic(ox, oy, 45.0, 20.0, 2.0, 1.0)
+    fin = np.isfinite(hm)
+    assert fin.sum() == 302
+    assert hm[fin].max() == 31.384776310850242
+    assert abs(hm[fin].sum() - 4588.116374840029) < 1e-9
+    r = m.plan(CONF, [10.0, 7.0, math.radians(120.0)], [45.0, 20.0, math.radians(90.0)])
+    assert r["status"] == 0
+    S = r["stats"]
+    assert S.expansions == 24 and S.stale_pops == 11
+    assert r["closed"][:12].tolist() == [7980, 8004, 7304, 6604, 5881, 4758, 4760, 4361, 4736,
+                                         3986, 3563, 3539]
+    assert S.rollouts == 78 * 23
+    assert S.poses_checked == 8951
+    assert S.rs_paths == 168
+    assert abs(S.rs_final_length - 28.9095829421864) < 1e-9
+    assert abs(r["cost"] - 561.4479147109321) < 1e-9
+    assert len(r["x"]) == 184
+    assert r["x"][0] == 10.0 and r["y"][0] == 7.0
+    assert abs(r["x"][-1] - 45.0) < 1e-9 and abs(r["y"][-1] - 20.0) < 1e-9

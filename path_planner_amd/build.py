@@ -1,0 +1,57 @@
+"""Build libpp_hip.so (hand-written HIP, gfx950 only) in-tree with hipcc.
+
+    python -m path_planner_amd.build [--force]
+
+-ffp-contract=off applies to host AND device code: the reference's arithmetic is a sequence of
+individually rounded multiplies and adds, and a fused multiply-add would change last bits.
+"""
+import concurrent.futures as cf
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(CSRC, "libpp_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    srcs = _sources()
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    objs, jobs = [], []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with cf.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(OUT, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

@@ -1,0 +1,45 @@
+// pp_expand.h -- launch parameters of the motion-primitive kernel, shared with the planner.
+#ifndef PP_EXPAND_H_
+#define PP_EXPAND_H_
+
+#include "pp_internal.h"
+
+struct PpExpandParams {
+  double step;        // conf.xy_reso * 2.0 (hybrid_astar.rs:260)
+  double move_step, wheel_base;
+  double xyreso, yawreso;
+  uint64_t minx, miny, maxx, maxy;
+  double backward_cost, gear_cost, steer_angle_cost, steer_change_cost;
+  uint32_t nlist;       // ceil(step / move_step) (:262)
+  uint32_t check_step;  // conf.collision_check_step
+};
+
+// Device output arrays, one entry per (parent, primitive).
+struct PpExpandDev {
+  uint8_t* valid;
+  uint64_t* xind;
+  uint64_t* yind;
+  int64_t* yawind;
+  double* cost;
+  double* end_x;
+  double* end_y;
+  double* end_yaw;
+};
+
+struct PpExpandPlan {
+  uint32_t n_prim = 0;
+  std::vector<double> motion;  // steer[n_prim], direc[n_prim], tan(steer)[n_prim]
+  pp_param param{};
+  PpExpandParams prm{};
+  PpFootprint fp{};
+};
+
+int32_t pp_expand_prepare(pp_ctx* ctx, const pp_map* map, const pp_config* conf, PpExpandPlan* plan);
+void pp_expand_launch(pp_ctx* ctx, const pp_map* map, const PpExpandPlan& plan, uint64_t n,
+                      const double* d_px, const double* d_py, const double* d_pyaw,
+                      const int64_t* d_pdir, const double* d_psteer, const double* d_pcost,
+                      const double* d_motion, PpExpandDev out);
+int32_t pp_rollout_points_batch(pp_ctx* ctx, const pp_config* conf, uint32_t n, const double* in5,
+                                double* x, double* y, double* yaw, uint32_t* nlist_out);
+
+#endif

@@ -1,0 +1,289 @@
+// pp_expand.hip -- motion-primitive rollouts with footprint checks
+// (calc_next_node + is_index_ok, hybrid_astar.rs:252-343) for a batch of parent nodes.
+//
+// One lane per (parent, primitive).  The yaw recurrence uses tan(u) from a host-computed table
+// (calc_motion_set yields only 2*n_steer-1 distinct steering angles), so every yaw of a rollout
+// is bit-identical to the reference; x and y accumulate device cos/sin.
+#include "pp_device.h"
+#include "pp_expand.h"
+
+__global__ void __launch_bounds__(256)
+k_expand(uint64_t n_items, uint32_t n_prim, const double* __restrict__ px,
+         const double* __restrict__ py, const double* __restrict__ pyaw,
+         const int64_t* __restrict__ pdir, const double* __restrict__ psteer,
+         const double* __restrict__ pcost, const double* __restrict__ motion, PpExpandParams prm,
+         PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice, PpExpandDev out) {
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += stride) {
+    uint64_t p = t / n_prim;
+    uint32_t i = (uint32_t)(t - p * n_prim);
+    double u = motion[i], d = motion[n_prim + i], tanu = motion[2 * n_prim + i];
+    double x = px[p], y = py[p], yaw = pyaw[p];
+    double dm = d * prm.move_step;            // d * conf.move_step
+    double dyaw = dm / prm.wheel_base * tanu;  // d * move_step / wheel_base * u.tan()
+    unsigned fl = 0;
+    bool hit = false;
+    uint32_t next_check = 0;
+    for (uint32_t k = 0; k <= prm.nlist; ++k) {
+      double s, c;
+      bool check = (k == next_check);
+      if (check || k < prm.nlist) sincos(yaw, &s, &c);
+      if (check) {
+        next_check += prm.check_step;
+        unsigned r = use_lattice ? pp_pose_vs_lattice(x, y, c, s, f, lat)
+                                 : pp_pose_vs_buckets(x, y, c, s, f, bk);
+        hit |= (r & PP_F_HIT) && !(r & PP_F_AMBIG);
+        fl |= r;
+      }
+      if (k < prm.nlist) {
+        double ax = dm * c, ay = dm * s;
+        x = x + ax;
+        y = y + ay;
+        yaw = yaw + dyaw;
+      }
+    }
+    double vx = x / prm.xyreso, vy = y / prm.xyreso, vyaw = yaw / prm.yawreso;
+    uint64_t xind = pp_sat_usize(round(vx));
+    uint64_t yind = pp_sat_usize(round(vy));
+    int64_t yawind = pp_sat_isize(round(vyaw));
+    bool in_bounds = !(xind <= prm.minx || xind >= prm.maxx || yind <= prm.miny || yind >= prm.maxy);
+    // rounding decisions within 1e-9 of a .5 tie could fall either way under another libm
+    bool tie = (fabs(fabs(vx - trunc(vx)) - 0.5) < 1e-9) || (fabs(fabs(vy - trunc(vy)) - 0.5) < 1e-9) ||
+               (fabs(fabs(vyaw - trunc(vyaw)) - 0.5) < 1e-9);
+    bool collide = (fl & PP_F_HIT) != 0;
+    bool amb = tie || (!hit && (fl & PP_F_AMBIG));
+    bool valid = in_bounds && !collide;
+
+    double step = prm.step;
+    double cost = 0.0;
+    int64_t direction;
+    if (d > 0.0) {
+      direction = 1;
+      cost += fabs(step);
+    } else {
+      direction = -1;
+      cost += fabs(step) * prm.backward_cost;
+    }
+    if (direction != pdir[p]) cost += prm.gear_cost;
+    cost += prm.steer_angle_cost * fabs(u);
+    cost += prm.steer_change_cost * fabs(psteer[p] - u);
+    cost += pcost[p];
+
+    unsigned v = (valid ? 1u : 0u) | (amb ? 2u : 0u) | ((fl & PP_F_NONFINITE) ? 4u : 0u);
+    out.valid[t] = (uint8_t)v;
+    out.xind[t] = valid ? xind : 0;
+    out.yind[t] = valid ? yind : 0;
+    out.yawind[t] = valid ? yawind : 0;
+    out.cost[t] = valid ? cost : 0.0;
+    out.end_x[t] = valid ? x : 0.0;
+    out.end_y[t] = valid ? y : 0.0;
+    out.end_yaw[t] = valid ? yaw : 0.0;
+  }
+}
+
+// The (nlist+1)-point lists of individual primitives (hybrid_astar.rs:266-274), for the nodes
+// extract_path walks.  One lane per primitive; out[(j * (nlist+1) + k)].
+__global__ void k_rollout_points(uint32_t n, uint32_t nlist, const double* __restrict__ in,
+                                 double move_step, double wheel_base, double* __restrict__ ox,
+                                 double* __restrict__ oy, double* __restrict__ oyaw) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double x = in[j * 5 + 0], y = in[j * 5 + 1], yaw = in[j * 5 + 2], tanu = in[j * 5 + 3],
+         d = in[j * 5 + 4];
+  double dm = d * move_step;
+  double dyaw = dm / wheel_base * tanu;
+  size_t o = (size_t)j * (nlist + 1);
+  ox[o] = x;
+  oy[o] = y;
+  oyaw[o] = yaw;
+  for (uint32_t k = 0; k < nlist; ++k) {
+    double s, c;
+    sincos(yaw, &s, &c);
+    double ax = dm * c, ay = dm * s;
+    x = x + ax;
+    y = y + ay;
+    yaw = yaw + dyaw;
+    ox[o + k + 1] = x;
+    oy[o + k + 1] = y;
+    oyaw[o + k + 1] = yaw;
+  }
+}
+
+// ---------------------------------------------------------------------------- host side
+
+// calc_motion_set, hybrid_astar.rs:495-514
+extern "C" int32_t pp_motion_set(const pp_config* conf, double* steer, double* direc, uint64_t cap,
+                                 uint64_t* n_out) {
+  if (!conf || !n_out || conf->n_steer == 0) return PP_ERR_INVALID;
+  uint64_t half = 2 * (conf->n_steer - 1) + 1;
+  *n_out = 2 * half;
+  if (cap < 2 * half) return PP_ERR_CAPACITY;
+  if (!steer || !direc) return PP_ERR_INVALID;
+  uint64_t ns = conf->n_steer - 1;
+  for (uint64_t i = 1; i < conf->n_steer; ++i) {
+    double v = (double)i * conf->max_steer / (double)conf->n_steer;
+    steer[i - 1] = v;
+    steer[ns + i] = -v;
+  }
+  steer[ns] = 0.0;
+  for (uint64_t i = 0; i < half; ++i) {
+    steer[half + i] = steer[i];
+    direc[i] = 1.0;
+    direc[half + i] = -1.0;
+  }
+  return PP_OK;
+}
+
+int32_t pp_expand_prepare(pp_ctx* ctx, const pp_map* map, const pp_config* conf, PpExpandPlan* plan) {
+  int32_t st = pp_check_config(conf);
+  if (st != PP_OK) return st;
+  uint64_t np = 0;
+  pp_motion_set(conf, nullptr, nullptr, 0, &np);
+  plan->n_prim = (uint32_t)np;
+  plan->motion.resize(3 * np);
+  pp_motion_set(conf, plan->motion.data(), plan->motion.data() + np, np, &np);
+  for (uint64_t i = 0; i < np; ++i) plan->motion[2 * np + i] = std::tan(plan->motion[i]);
+  pp_param P;
+  pp_map_param(map, conf, &P);
+  plan->param = P;
+  PpExpandParams& q = plan->prm;
+  q.step = conf->xy_reso * 2.0;
+  double nl = std::ceil(q.step / conf->move_step);
+  if (!(nl >= 0.0) || nl > 1.0e6) return PP_ERR_INVALID;
+  q.nlist = (uint32_t)pp_sat_usize(nl);
+  q.check_step = (uint32_t)std::min<uint64_t>(conf->collision_check_step, 0x7fffffffu);
+  q.move_step = conf->move_step;
+  q.wheel_base = conf->car.wheel_base;
+  q.xyreso = P.xyreso;
+  q.yawreso = P.yawreso;
+  q.minx = P.minx;
+  q.miny = P.miny;
+  q.maxx = P.maxx;
+  q.maxy = P.maxy;
+  q.backward_cost = conf->backward_cost;
+  q.gear_cost = conf->gear_cost;
+  q.steer_angle_cost = conf->steer_angle_cost;
+  q.steer_change_cost = conf->steer_change_cost;
+  plan->fp = pp_make_footprint(conf);
+  (void)ctx;
+  return PP_OK;
+}
+
+void pp_expand_launch(pp_ctx* ctx, const pp_map* map, const PpExpandPlan& plan, uint64_t n,
+                      const double* d_px, const double* d_py, const double* d_pyaw,
+                      const int64_t* d_pdir, const double* d_psteer, const double* d_pcost,
+                      const double* d_motion, PpExpandDev out) {
+  uint64_t items = n * plan.n_prim;
+  const unsigned block = 256;
+  unsigned grid = pp_stream_grid(ctx, items, block);
+  hipLaunchKernelGGL(k_expand, dim3(grid), dim3(block), 0, ctx->stream, items, plan.n_prim, d_px,
+                     d_py, d_pyaw, d_pdir, d_psteer, d_pcost, d_motion, plan.prm, plan.fp, map->lat,
+                     map->bk, map->lattice ? 1 : 0, out);
+}
+
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" int32_t pp_expand_batch(pp_ctx* ctx, const pp_map* map, const pp_config* conf,
+                                   uint64_t n, const double* px, const double* py,
+                                   const double* pyaw, const int64_t* pdir, const double* psteer,
+                                   const double* pcost, pp_expand_out* out) {
+  if (!ctx || !map || !conf || !out) return PP_ERR_INVALID;
+  if (map->ox.empty()) return PP_ERR_EMPTY_MAP;
+  if (!map->finite) return PP_ERR_NONFINITE;
+  if (n == 0) return PP_OK;
+  if (!px || !py || !pyaw || !pdir || !psteer || !pcost) return PP_ERR_INVALID;
+  PpExpandPlan plan;
+  int32_t st = pp_expand_prepare(ctx, map, conf, &plan);
+  if (st != PP_OK) return st;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  uint64_t items = n * plan.n_prim;
+  size_t in_b = al256(n * 8), mot_b = al256(plan.motion.size() * 8);
+  size_t o8 = al256(items * 8), o1 = al256(items);
+  st = pp_scratch_reserve(ctx, 6 * in_b + mot_b + 7 * o8 + o1);
+  if (st != PP_OK) return st;
+  char* b = (char*)ctx->scratch;
+  double* d_px = (double*)b; b += in_b;
+  double* d_py = (double*)b; b += in_b;
+  double* d_pyaw = (double*)b; b += in_b;
+  int64_t* d_pdir = (int64_t*)b; b += in_b;
+  double* d_ps = (double*)b; b += in_b;
+  double* d_pc = (double*)b; b += in_b;
+  double* d_mot = (double*)b; b += mot_b;
+  PpExpandDev o;
+  o.xind = (uint64_t*)b; b += o8;
+  o.yind = (uint64_t*)b; b += o8;
+  o.yawind = (int64_t*)b; b += o8;
+  o.cost = (double*)b; b += o8;
+  o.end_x = (double*)b; b += o8;
+  o.end_y = (double*)b; b += o8;
+  o.end_yaw = (double*)b; b += o8;
+  o.valid = (uint8_t*)b;
+  hipStream_t s = ctx->stream;
+  PP_HIP(ctx, hipMemcpyAsync(d_px, px, n * 8, hipMemcpyHostToDevice, s));
+  PP_HIP(ctx, hipMemcpyAsync(d_py, py, n * 8, hipMemcpyHostToDevice, s));
+  PP_HIP(ctx, hipMemcpyAsync(d_pyaw, pyaw, n * 8, hipMemcpyHostToDevice, s));
+  PP_HIP(ctx, hipMemcpyAsync(d_pdir, pdir, n * 8, hipMemcpyHostToDevice, s));
+  PP_HIP(ctx, hipMemcpyAsync(d_ps, psteer, n * 8, hipMemcpyHostToDevice, s));
+  PP_HIP(ctx, hipMemcpyAsync(d_pc, pcost, n * 8, hipMemcpyHostToDevice, s));
+  PP_HIP(ctx, hipMemcpyAsync(d_mot, plan.motion.data(), plan.motion.size() * 8, hipMemcpyHostToDevice, s));
+  pp_expand_launch(ctx, map, plan, n, d_px, d_py, d_pyaw, d_pdir, d_ps, d_pc, d_mot, o);
+  PP_HIP(ctx, hipGetLastError());
+  PP_HIP(ctx, hipMemcpyAsync(out->valid, o.valid, items, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(out->xind, o.xind, items * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(out->yind, o.yind, items * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(out->yawind, o.yawind, items * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(out->cost, o.cost, items * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(out->end_x, o.end_x, items * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(out->end_y, o.end_y, items * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(out->end_yaw, o.end_yaw, items * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipStreamSynchronize(s));
+  for (uint64_t t = 0; t < items; ++t)
+    if (out->valid[t] & 4) return PP_ERR_NONFINITE;
+  return PP_OK;
+}
+
+int32_t pp_rollout_points_batch(pp_ctx* ctx, const pp_config* conf, uint32_t n,
+                                const double* in5 /* x,y,yaw,u,d per item */, double* x, double* y,
+                                double* yaw, uint32_t* nlist_out) {
+  double step = conf->xy_reso * 2.0;
+  uint32_t nlist = (uint32_t)pp_sat_usize(std::ceil(step / conf->move_step));
+  if (nlist_out) *nlist_out = nlist;
+  if (n == 0) return PP_OK;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<double> in(in5, in5 + (size_t)n * 5);
+  for (uint32_t j = 0; j < n; ++j) in[j * 5 + 3] = std::tan(in[j * 5 + 3]);
+  size_t pts = (size_t)n * (nlist + 1);
+  size_t in_b = al256(in.size() * 8), o_b = al256(pts * 8);
+  int32_t st = pp_scratch_reserve(ctx, in_b + 3 * o_b);
+  if (st != PP_OK) return st;
+  char* b = (char*)ctx->scratch;
+  double* d_in = (double*)b; b += in_b;
+  double* d_x = (double*)b; b += o_b;
+  double* d_y = (double*)b; b += o_b;
+  double* d_yaw = (double*)b;
+  hipStream_t s = ctx->stream;
+  PP_HIP(ctx, hipMemcpyAsync(d_in, in.data(), in.size() * 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_rollout_points, dim3((n + 63) / 64), dim3(64), 0, s, n, nlist, d_in,
+                     conf->move_step, conf->car.wheel_base, d_x, d_y, d_yaw);
+  PP_HIP(ctx, hipGetLastError());
+  PP_HIP(ctx, hipMemcpyAsync(x, d_x, pts * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(y, d_y, pts * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(yaw, d_yaw, pts * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipStreamSynchronize(s));
+  return PP_OK;
+}
+
+extern "C" int32_t pp_rollout_points(pp_ctx* ctx, const pp_config* conf, double x0, double y0,
+                                     double yaw0, double u, double d, double* x, double* y,
+                                     double* yaw, uint64_t cap, uint64_t* n_out) {
+  if (!ctx || !conf || !n_out) return PP_ERR_INVALID;
+  int32_t st = pp_check_config(conf);
+  if (st != PP_OK) return st;
+  double step = conf->xy_reso * 2.0;
+  uint64_t nlist = pp_sat_usize(std::ceil(step / conf->move_step));
+  *n_out = nlist + 1;
+  if (cap < nlist + 1) return PP_ERR_CAPACITY;
+  if (!x || !y || !yaw) return PP_ERR_INVALID;
+  double in5[5] = {x0, y0, yaw0, u, d};
+  return pp_rollout_points_batch(ctx, conf, 1, in5, x, y, yaw, nullptr);
+}

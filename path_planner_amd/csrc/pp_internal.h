@@ -1,0 +1,121 @@
+// pp_internal.h -- host-side structures shared by the translation units of libpp_hip.so.
+#ifndef PP_INTERNAL_H_
+#define PP_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/pp.h"
+
+// ---------------------------------------------------------------- device-visible PODs
+
+// Footprint rectangle of hybrid_astar.rs:418-421 plus the constants the kernels derive from it.
+struct PpFootprint {
+  double cp2center;   // (center2front - center2back) / 2
+  double bound_len;   // half length + extend_bound
+  double bound_wid;   // half width + extend_bound
+  double bound_radius;  // hypot(bound_len, bound_wid)
+  double r2_max;      // largest t with sqrt(t) <= bound_radius (sqrt correctly rounded):
+                      // `sqrt(s) <= bound_radius`  <=>  `s <= r2_max`
+  double guard;       // guard band for "a different libm could decide otherwise"
+};
+
+// Occupancy of an integer-lattice obstacle set, bit-packed and tiled for gather locality.
+//   tile  = 32 x 32 cells = 128 B (one cache line), tiles stored row-major (ty * tiles_x + tx)
+//   block = 16 wide x 8 tall cells = 16 B (one dwordx4 gather); a tile holds 2 x 4 blocks,
+//           block (bx, by) of the tile at uint4 index by * 2 + bx
+//   word  = 32 bits of a block: rows 2k (low half) and 2k+1 (high half), bit = column
+// Cell (cx, cy) in lattice coordinates maps to grid coordinates (cx - x0, cy - y0); the grid is
+// padded with one ring of empty tiles so window clamping never needs a per-load bounds test.
+struct PpLattice {
+  const uint4* tiles;
+  int32_t tiles_x, tiles_y;
+  int32_t nx, ny;      // cells including padding (multiples of 32)
+  int64_t x0, y0;      // lattice coordinate of grid cell (0, 0)
+};
+
+// General (non-lattice) obstacle points in unit-square buckets, CSR by row-major bucket index;
+// points of one bucket row are contiguous, so a window row is one [start, end) range.
+struct PpBuckets {
+  const uint32_t* start;  // nbx * nby + 1 entries
+  const double* px;       // points sorted by bucket
+  const double* py;
+  int64_t bx0, by0;       // bucket (0,0) covers [bx0, bx0+1) x [by0, by0+1)
+  int32_t nbx, nby;
+};
+
+// ---------------------------------------------------------------- host objects
+
+struct pp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int last_hip_error = 0;
+  int num_cus = 256;
+  // reusable device scratch (grown on demand, never shrunk)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+};
+
+struct pp_map {
+  pp_ctx* ctx = nullptr;
+  std::vector<double> ox, oy;  // the reference's lists, kept for calc_parameters / obsmap
+  bool finite = true;
+  bool lattice = false;
+  double minx = 0, miny = 0, maxx = 0, maxy = 0;
+  // device
+  uint4* d_tiles = nullptr;
+  PpLattice lat{};
+  uint32_t* d_bstart = nullptr;
+  double* d_bpx = nullptr;
+  double* d_bpy = nullptr;
+  PpBuckets bk{};
+  double* d_ox = nullptr;  // obstacle lists on the device (for the obstacle-raster kernel)
+  double* d_oy = nullptr;
+};
+
+#define PP_HIP(ctx, expr)                               \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) {                             \
+      if (ctx) (ctx)->last_hip_error = (int)e_;         \
+      return PP_ERR_HIP;                                \
+    }                                                   \
+  } while (0)
+
+int32_t pp_scratch_reserve(pp_ctx* ctx, size_t bytes);
+int32_t pp_pinned_reserve(pp_ctx* ctx, size_t bytes);
+PpFootprint pp_make_footprint(const pp_config* conf);
+int32_t pp_check_config(const pp_config* conf);
+
+// Rust `as usize` / `as isize` on f64 (saturating, NaN -> 0); host and device.
+__host__ __device__ inline uint64_t pp_sat_usize(double v) {
+  if (!(v == v)) return 0;
+  if (v <= 0.0) return 0;
+  if (v >= 18446744073709551615.0) return UINT64_MAX;
+  return (uint64_t)v;
+}
+__host__ __device__ inline int64_t pp_sat_isize(double v) {
+  if (!(v == v)) return 0;
+  if (v <= -9223372036854775808.0) return INT64_MIN;
+  if (v >= 9223372036854775807.0) return INT64_MAX;
+  return (int64_t)v;
+}
+
+// Launch geometry for one-item-per-lane streaming kernels: enough workgroups to fill 256 CUs
+// several times over, grid-stride for the rest.
+inline unsigned pp_stream_grid(const pp_ctx* ctx, uint64_t n, unsigned block) {
+  uint64_t need = (n + block - 1) / block;
+  uint64_t cap = (uint64_t)ctx->num_cus * 16;
+  if (need > cap) need = cap;
+  if (need == 0) need = 1;
+  return (unsigned)need;
+}
+
+#endif

@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Benchmark of the hybrid A* hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload collision|rs|wavefront]
+
+Default workload: BASELINE.json configs[1] -- batched footprint collision check, 16 777 216
+random SE(2) poses on a 2048x2048 occupancy grid (border + Bernoulli 0.05), demo car.  One
+"step" = one pass of the collision kernel over the whole pose batch, inputs resident in HBM.
+Multi-GPU (--gpus N under torch.distributed.run): every rank checks its own 16M-pose slice of the
+stream against a replicated grid (weak scaling, no data-path collective).
+
+Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (25 B/pose:
+3 x f64 in + 1 flag byte out) / the kernel's mean launch duration measured with events on the
+stream the kernel is launched on.  `cpu_baseline` = the CPU oracle (a port of the reference's
+is_collision) timed on this host on a bounded sample of the same poses.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+BYTES_PER_POSE = 25.0
+BYTES_PER_PAIR = 104.0
+BYTES_PER_CELL = 9.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="collision", choices=["collision", "rs", "wavefront"])
+    ap.add_argument("--poses", type=int, default=1 << 24)
+    ap.add_argument("--grid", type=int, default=2048)
+    ap.add_argument("--pairs", type=int, default=1 << 20)
+    ap.add_argument("--cells", type=int, default=16384, help="wavefront grid edge")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0)
+    return ap.parse_args()
+
+
+def traffic_from_profile(name):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (profiles/traffic.json), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get(name)
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from path_planner_amd import _abi as A
+    from path_planner_amd import api
+    from path_planner_amd import workloads as W
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    stream = torch.cuda.Stream(device=dev)
+    ctx = api.Context(local_rank, stream.cuda_stream)
+    conf = A.demo_config()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ set-up
+    if args.workload == "collision":
+        occ = W.occupancy_grid(args.grid, 0.05)
+        omap = api.ObstacleMap(ctx, raster=occ)
+        n = args.poses
+        x, y, yaw = W.random_poses(n, args.grid, start=rank * n)
+        dx, dy, dyaw = (torch.from_numpy(a).to(dev) for a in (x, y, yaw))
+        flags = torch.zeros(n, dtype=torch.uint8, device=dev)
+        units, bytes_per_unit = n, BYTES_PER_POSE
+        metric, unit = "collision_checked_poses_per_sec", "poses/s"
+        wl = {"workload": f"footprint collision, {n} SE(2) poses/GPU on {args.grid}x{args.grid} "
+                          "occupancy grid (border + Bernoulli 0.05), demo car",
+              "poses_per_gpu": n, "grid": args.grid, "parallelism": f"pose-sharded x{world}"}
+        dtype, kernel = "f64", "k_collision"
+
+        def step():
+            api.collision_flags_dev(ctx, omap, conf, dx, dy, dyaw, flags)
+    elif args.workload == "rs":
+        n = args.pairs
+        q0, q1 = W.rs_pairs(n, start=rank * n)
+        cols = [torch.from_numpy(np.ascontiguousarray(q[:, k])).to(dev) for q in (q0, q1) for k in range(3)]
+        npaths = torch.zeros(n, dtype=torch.int32, device=dev)
+        best = torch.zeros(n, dtype=torch.int32, device=dev)
+        words = torch.zeros(n * 56, dtype=torch.uint8, device=dev)
+        rflags = torch.zeros(n, dtype=torch.uint8, device=dev)
+        maxc = W.demo_maxc()
+        units, bytes_per_unit = n, BYTES_PER_PAIR
+        metric, unit = "reeds_shepp_pairs_per_sec", "pairs/s"
+        wl = {"workload": f"Reeds-Shepp all families + argmin, {n} pairs/GPU", "pairs_per_gpu": n,
+              "parallelism": f"pair-sharded x{world}"}
+        dtype, kernel = "f64", "k_rs_batch"
+
+        def step():
+            st = ctx.lib.pp_rs_batch_dev(ctx.h, n, *[c.data_ptr() for c in cols], maxc,
+                                         npaths.data_ptr(), best.data_ptr(), words.data_ptr(),
+                                         rflags.data_ptr())
+            assert st == 0, st
+    else:
+        ncell = args.cells
+        obs_np, gx, gy = W.wavefront_obsmap(ncell, 0.2)
+        obs = torch.from_numpy(obs_np).to(dev)
+        cost = torch.empty((ncell, ncell), dtype=torch.float64, device=dev)
+        units, bytes_per_unit = ncell * ncell, BYTES_PER_CELL
+        metric, unit = "heuristic_cells_per_sec", "cells/s"
+        wl = {"workload": f"holonomic heuristic wavefront, {ncell}x{ncell} grid (border + "
+                          "Bernoulli 0.2), goal at centre", "cells": ncell * ncell,
+              "parallelism": f"replicas x{world}"}
+        dtype, kernel = "f64", "k_wave_*"
+
+        def step():
+            api.wavefront_dev(ctx, obs, gx, gy, cost)
+
+    # ------------------------------------------------------------------ timed region
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(args.steps):
+            step()
+        ev1.record(stream)
+        barrier()
+        t1 = time.perf_counter()
+    elapsed = t1 - t0
+    dev_ms = ev0.elapsed_time(ev1) / args.steps  # mean duration of one launch on its stream
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_units = units * world * args.steps
+    value = total_units / elapsed
+
+    out = {
+        "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic", "config": wl,
+    }
+    achieved = units * bytes_per_unit / (dev_ms * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(args.workload),
+                       "kernel": kernel, "kernel_ms": dev_ms, "bytes_per_unit": bytes_per_unit}
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        if args.workload == "collision":
+            ox, oy = W.raster_to_points(occ)
+            om = O.OracleMap(ox, oy)
+            ns = args.cpu_sample or min(n, 1 << 23)  # ~10 s single-threaded
+            t0 = time.perf_counter()
+            st, ef = om.collision_flags(conf, x[:ns], y[:ns], yaw[:ns])
+            dt = time.perf_counter() - t0
+            got = flags[:ns].cpu().numpy()
+            mism = int(((got & 1) != ef).sum())
+            ncpu = min(os.cpu_count() or 1, 16)
+            t0 = time.perf_counter()
+            om.collision_flags(conf, x[:ns], y[:ns], yaw[:ns], threads=ncpu)
+            dtm = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": ns / dt, "unit": unit, "cores": 1, "kind": "port",
+                                   "sample": f"first {ns} poses of the same batch, CPU oracle "
+                                             "(is_collision restated, bucket-grid candidate filter)",
+                                   "flag_mismatches_vs_gpu": mism,
+                                   "all_cores": {"value": ns / dtm, "cores": ncpu}}
+        elif args.workload == "rs":
+            ns = args.cpu_sample or min(n, 1 << 18)
+            t0 = time.perf_counter()
+            O.rs_batch(q0[:ns], q1[:ns], maxc, threads=1)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": ns / dt, "unit": unit, "cores": 1, "kind": "port",
+                                   "sample": f"first {ns} pairs, CPU oracle generate_path + argmin"}
+        else:
+            ns = args.cpu_sample or min(ncell, 2048)
+            sub = np.ascontiguousarray(obs_np[:ns, :ns]).copy()
+            sub[0, :] = sub[-1, :] = 1
+            sub[:, 0] = sub[:, -1] = 1
+            sub[ns // 2, ns // 2] = 0
+            t0 = time.perf_counter()
+            O.wavefront(sub, ns // 2, ns // 2)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": ns * ns / dt, "unit": unit, "cores": 1, "kind": "port",
+                                   "sample": f"{ns}x{ns} corner of the same raster, CPU oracle "
+                                             "Dijkstra (dense arrays, binary heap)"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,10 +149,8 @@ static int32_t build_lattice(pp_ctx* ctx, pp_map* m, const std::vector<int64_t>&
   for (size_t i = 0; i < ix.size(); ++i) {
     int64_t gx = ix[i] - x0, gy = iy[i] - y0;
     size_t tile = (size_t)(gy >> 5) * tx + (size_t)(gx >> 5);
-    int bx = (int)((gx >> 4) & 1), by = (int)((gy >> 3) & 3);
-    int row = (int)(gy & 7), col = (int)(gx & 15);
-    size_t word = tile * 32 + (size_t)(by * 2 + bx) * 4 + (size_t)(row >> 1);
-    words[word] |= 1u << ((row & 1) * 16 + col);
+    size_t word = tile * 32 + (size_t)(gy & 31);  // block (gy >> 2) & 7, row gy & 3
+    words[word] |= 1u << (gx & 31);
   }
   PP_HIP(ctx, hipMalloc((void**)&m->d_tiles, nwords * sizeof(uint32_t)));
   PP_HIP(ctx, hipMemcpy(m->d_tiles, words.data(), nwords * sizeof(uint32_t), hipMemcpyHostToDevice));

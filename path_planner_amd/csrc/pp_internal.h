@@ -26,9 +26,9 @@ struct PpFootprint {
 
 // Occupancy of an integer-lattice obstacle set, bit-packed and tiled for gather locality.
 //   tile  = 32 x 32 cells = 128 B (one cache line), tiles stored row-major (ty * tiles_x + tx)
-//   block = 16 wide x 8 tall cells = 16 B (one dwordx4 gather); a tile holds 2 x 4 blocks,
-//           block (bx, by) of the tile at uint4 index by * 2 + bx
-//   word  = 32 bits of a block: rows 2k (low half) and 2k+1 (high half), bit = column
+//   block = 32 wide x 4 tall cells = 16 B (one dwordx4 gather); a tile stacks 8 blocks,
+//           block of row y at uint4 index (y >> 2) & 7
+//   word  = one row of a block: bit = column & 31
 // Cell (cx, cy) in lattice coordinates maps to grid coordinates (cx - x0, cy - y0); the grid is
 // padded with one ring of empty tiles so window clamping never needs a per-load bounds test.
 struct PpLattice {

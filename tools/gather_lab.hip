@@ -1,0 +1,61 @@
+// gather_lab.hip -- development harness: cost of per-lane 16-B gathers from a 544 KiB table
+// (L2-resident) by placement of the addresses within 128-B lines.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+__device__ inline uint64_t mix(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// V: 1 = one block; 2 = blocks 0,1 of a line; 3 = blocks 0,4; 4 = two different lines;
+//    5 = blocks 0..3; 6 = blocks 0..7; 7 = 8-byte loads x1 ; 8 = 4-byte x1; 9 = 4 different lines
+template <int V>
+__global__ void __launch_bounds__(256) k(uint64_t n, const uint4* __restrict__ t, uint32_t nlines, const double* __restrict__ x, uint8_t* out) {
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double xv = x[i];
+    uint64_t h = mix(i * 0x9E3779B97F4A7C15ull + (uint64_t)(xv));
+    uint32_t l0 = (uint32_t)(h % nlines), l1 = (uint32_t)((h >> 32) % nlines);
+    uint32_t l2 = (uint32_t)((h >> 16) % nlines), l3 = (uint32_t)((h >> 8) % nlines);
+    unsigned acc = 0;
+    auto ld = [&](uint32_t line, int blk) { uint4 b = t[(size_t)line * 8 + blk]; acc |= b.x ^ b.y ^ b.z ^ b.w; };
+    if (V == 1) ld(l0, 0);
+    if (V == 2) { ld(l0, 0); ld(l0, 1); }
+    if (V == 3) { ld(l0, 0); ld(l0, 4); }
+    if (V == 4) { ld(l0, 0); ld(l1, 0); }
+    if (V == 5) { ld(l0, 0); ld(l0, 1); ld(l0, 2); ld(l0, 3); }
+    if (V == 6) { for (int b = 0; b < 8; ++b) ld(l0, b); }
+    if (V == 7) { uint2 b = ((const uint2*)t)[(size_t)l0 * 16]; acc |= b.x ^ b.y; }
+    if (V == 8) { acc |= ((const uint32_t*)t)[(size_t)l0 * 32]; }
+    if (V == 9) { ld(l0, 0); ld(l1, 0); ld(l2, 0); ld(l3, 0); }
+    out[i] = (uint8_t)acc;
+  }
+}
+int main() {
+  uint64_t n = 1 << 24; uint32_t nlines = 4356;  // 66x66 tiles of 128 B = 544.5 KiB
+  uint4* t; double* x; uint8_t* o;
+  CK(hipMalloc(&t, (size_t)nlines * 128)); CK(hipMemset(t, 1, (size_t)nlines * 128));
+  CK(hipMalloc(&x, n * 8)); CK(hipMemset(x, 0, n * 8)); CK(hipMalloc(&o, n));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto run = [&](auto kern, const char* name) {
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(4096), dim3(256), 0, 0, n, t, nlines, x, o);
+    CK(hipEventRecord(e0));
+    for (int w = 0; w < 10; ++w) hipLaunchKernelGGL(kern, dim3(4096), dim3(256), 0, 0, n, t, nlines, x, o);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+    printf("%-40s %8.3f ms\n", name, ms);
+  };
+  run(k<0>, "no gather (8B read + 1B write)");
+  run(k<8>, "1 x 4B");
+  run(k<7>, "1 x 8B");
+  run(k<1>, "1 x 16B");
+  run(k<2>, "2 x 16B same 64B sector");
+  run(k<3>, "2 x 16B same line, other half");
+  run(k<4>, "2 x 16B different lines");
+  run(k<5>, "4 x 16B same 64B half-line... (0..3)");
+  run(k<6>, "8 x 16B whole line");
+  run(k<9>, "4 x 16B different lines");
+  return 0;
+}

@@ -117,6 +117,11 @@ PpFootprint pp_make_footprint(const pp_config* conf) {
   }
   f.r2_max = t;
   f.guard = 1.0e-11;
+  const double inflate = 2.5e-4;
+  f.scan_lo = std::nextafter((float)(f.bound_len + inflate), 1e30f);
+  f.scan_wo = std::nextafter((float)(f.bound_wid + inflate), 1e30f);
+  f.scan_ok = (std::isfinite(f.bound_radius) && f.bound_radius + 2.0 * inflate <= 6.0 &&
+               f.bound_len >= 0.0 && f.bound_wid >= 0.0) ? 1 : 0;
   return f;
 }
 
@@ -142,21 +147,20 @@ static int32_t build_lattice(pp_ctx* ctx, pp_map* m, const std::vector<int64_t>&
   int64_t x0 = (lo_x & ~(int64_t)31) - 32, y0 = (lo_y & ~(int64_t)31) - 32;
   int64_t nx = ((hi_x - x0) / 32 + 2) * 32, ny = ((hi_y - y0) / 32 + 2) * 32;
   if (nx > (1 << 24) || ny > (1 << 24)) return PP_ERR_UNSUPPORTED;
-  int32_t tx = (int32_t)(nx / 32), ty = (int32_t)(ny / 32);
-  size_t nwords = (size_t)tx * ty * 32;
+  int32_t nstrips = (int32_t)(nx / 32), nbrows = (int32_t)(ny / 4);
+  size_t nwords = (size_t)nstrips * (size_t)nbrows * 4;
   if (nwords > ((size_t)1 << 33)) return PP_ERR_UNSUPPORTED;
   std::vector<uint32_t> words(nwords, 0u);
   for (size_t i = 0; i < ix.size(); ++i) {
     int64_t gx = ix[i] - x0, gy = iy[i] - y0;
-    size_t tile = (size_t)(gy >> 5) * tx + (size_t)(gx >> 5);
-    size_t word = tile * 32 + (size_t)(gy & 31);  // block (gy >> 2) & 7, row gy & 3
+    size_t word = ((size_t)(gx >> 5) * (size_t)nbrows + (size_t)(gy >> 2)) * 4 + (size_t)(gy & 3);
     words[word] |= 1u << (gx & 31);
   }
   PP_HIP(ctx, hipMalloc((void**)&m->d_tiles, nwords * sizeof(uint32_t)));
   PP_HIP(ctx, hipMemcpy(m->d_tiles, words.data(), nwords * sizeof(uint32_t), hipMemcpyHostToDevice));
-  m->lat.tiles = m->d_tiles;
-  m->lat.tiles_x = tx;
-  m->lat.tiles_y = ty;
+  m->lat.blocks = m->d_tiles;
+  m->lat.nstrips = nstrips;
+  m->lat.nbrows = nbrows;
   m->lat.nx = (int32_t)nx;
   m->lat.ny = (int32_t)ny;
   m->lat.x0 = x0;

@@ -48,22 +48,25 @@ __device__ __forceinline__ void pp_footprint_centre(double x, double y, double c
 }
 
 // ---------------------------------------------------------------------------------------------
-// Bit-packed lattice.  A block is 32 columns x 4 rows (one uint4, word r = row r, bit = column);
-// a 128-B tile stacks 8 blocks (32 x 32 cells); see PpLattice.
+// Bit-packed lattice (layout: PpLattice in pp_internal.h).
 
 __device__ __forceinline__ uint4 pp_lattice_block(const PpLattice& g, int col, int brow) {
-  // col: any column of the block; brow: row >> 2
-  size_t addr = ((size_t)(brow >> 3) * (size_t)g.tiles_x + (size_t)(col >> 5)) * 8 + (size_t)(brow & 7);
-  return g.tiles[addr];
+  return g.blocks[(size_t)(col >> 5) * (size_t)g.nbrows + (size_t)brow];
 }
 
 // Exhaustive form: the exact predicate on every occupied cell of the rotated rectangle's
-// bounding box [ix0..ix1] x [iy0..iy1] (grid coordinates).  Cells outside that box (it is
-// enlarged by 1e-6) can never pass the rectangle test, so skipping them leaves the reference's
-// any-hit result unchanged.
-__device__ __noinline__ unsigned pp_lattice_scan_exact(double cx, double cy, double c, double s,
-                                                       int ix0, int ix1, int iy0, int iy1,
-                                                       const PpFootprint& f, const PpLattice& g) {
+// bounding box (enlarged by 1e-6, clamped to the grid).  Cells outside that box can never pass
+// the rectangle test, so skipping them leaves the reference's any-hit result unchanged.
+__device__ __forceinline__ unsigned pp_lattice_scan_exact(double cx, double cy, double gx, double gy,
+                                                          double c, double s, const PpFootprint& f,
+                                                          const PpLattice& g) {
+  double ac = fabs(c), as = fabs(s);
+  double hx = ac * f.bound_len + as * f.bound_wid + 1.0e-6;
+  double hy = as * f.bound_len + ac * f.bound_wid + 1.0e-6;
+  double fx0 = fmax(ceil(gx - hx), 0.0), fx1 = fmin(floor(gx + hx), (double)(g.nx - 1));
+  double fy0 = fmax(ceil(gy - hy), 0.0), fy1 = fmin(floor(gy + hy), (double)(g.ny - 1));
+  if (!(fx0 <= fx1) || !(fy0 <= fy1)) return 0;
+  int ix0 = (int)fx0, ix1 = (int)fx1, iy0 = (int)fy0, iy1 = (int)fy1;
   bool amb = false, ahit = false;
   for (int y = iy0; y <= iy1; ++y) {
     for (int xb = ix0 & ~31; xb <= ix1; xb += 32) {
@@ -87,95 +90,111 @@ __device__ __noinline__ unsigned pp_lattice_scan_exact(double cx, double cy, dou
   return ahit ? (PP_F_HIT | PP_F_AMBIG) : (amb ? PP_F_AMBIG : 0u);
 }
 
-// Scanline form.  The rectangle, inflated by PP_SCAN_MARGIN on every side, is rasterised row by
-// row in fp32: for window row y the inflated rectangle spans [lo(y), hi(y)], with
-//   lo(y) = xL + max((y - yL) * m1, (y - yL) * m2),  hi(y) = xR + min((y - yR) * m1, (y - yR) * m2)
-// where (xL, yL) / (xR, yR) are its leftmost / rightmost vertices and m1 = c/s, m2 = -s/c are
-// the dx/dy slopes of its edges.  fp32 evaluation errors (< 5e-5 cells for window coordinates
-// below 64) are far inside the inflation, so the row masks cover every cell the exact predicate
-// could accept: no occupied cell under the masks => miss.  An occupied cell under a mask is then
-// put to the exact fp64 predicate; a clear hit settles the pose, anything else (the cell sits in
-// the thin band between the true and the inflated rectangle) falls back to the exhaustive form.
-#define PP_SCAN_MARGIN 2.5e-4
+// Four window rows (one block row) of the scanline test; see pp_pose_vs_lattice.  `key` keeps
+// one candidate: (occupied bits under the row mask) << 4 | window row, maximised over rows, so
+// key >= 16 iff some row had a candidate.
+struct PpScan {
+  float xL, yL, xR1, yR, m1, m2;
+  unsigned sh;
+};
+template <int J0>
+__device__ __forceinline__ unsigned pp_scan_rows4(const PpScan& q, uint4 lb, uint4 rb, unsigned key) {
+  const unsigned lw[4] = {lb.x, lb.y, lb.z, lb.w};
+  const unsigned rw[4] = {rb.x, rb.y, rb.z, rb.w};
+  unsigned k[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float yr = (float)(J0 + r);
+    const float t = yr - q.yL, t2 = yr - q.yR;
+    // lo clamped below at 0 and hi above at 24 by the three-operand max/min
+    const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(t, q.m1, q.xL), __builtin_fmaf(t, q.m2, q.xL)), 0.0f);
+    const float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaf(t2, q.m1, q.xR1), __builtin_fmaf(t2, q.m2, q.xR1)), 24.0f);
+    const float cl = __builtin_ceilf(lo);
+    const float wf = __builtin_floorf(hi) - cl;  // cells cl .. floor(hi) - 1 (xR1 carries the +1)
+    const float wc = __builtin_fmaxf(wf, 0.0f);
+    const unsigned w = (unsigned)wc, ilo = (unsigned)__builtin_fminf(cl, 31.0f);
+    const unsigned mask = ((1u << w) - 1u) << ilo;
+    const unsigned bits = __builtin_amdgcn_alignbit(rw[r], lw[r], q.sh);
+    k[r] = ((bits & mask) << 4) | (unsigned)(J0 + r);
+  }
+  return max(max(key, k[0]), max(max(k[1], k[2]), k[3]));
+}
 
+// Scanline form, for footprints whose bounding radius is below 6 cells (f.scan_ok).  The window
+// is the 13 columns floor(gx)-6 .. +6 by the 16 rows of the four block rows that cover
+// floor(gy)-6 .. +6.  The rectangle, inflated by f.scan_lo/scan_wo - bound (2.5e-4) on every
+// side, is rasterised row by row in fp32: window row y spans [lo(y), hi(y)] with
+//   lo(y) = xL + max((y - yL) * m1, (y - yL) * m2),  hi(y) = xR + min((y - yR) * m1, (y - yR) * m2)
+// where (xL, yL) / (xR, yR) are the leftmost / rightmost vertices and m1 = c/s, m2 = -s/c the
+// dx/dy slopes of the edges.  fp32 evaluation errors (< 5e-5 cells at window coordinates below
+// 32) are far inside the inflation, so the row masks cover every cell the exact predicate could
+// accept: no occupied cell under the masks => miss.  One occupied cell under a mask is put to
+// the exact fp64 predicate; a clear hit settles the pose, anything else (the cell sits in the
+// thin band between the true and the inflated rectangle) falls back to the exhaustive form.
+// The two central block rows are fetched first; the outer two only by lanes still undecided.
 __device__ __forceinline__ unsigned pp_pose_vs_lattice(double x, double y, double c, double s,
                                                        const PpFootprint& f, const PpLattice& g) {
   double cx, cy;
   pp_footprint_centre(x, y, c, s, f, cx, cy);
   if (!(fabs(cx) < 1.0e300) || !(fabs(cy) < 1.0e300)) return PP_F_NONFINITE;
-  double ac = fabs(c), as = fabs(s);
-  double ex = ac * f.bound_len + as * f.bound_wid;
-  double ey = as * f.bound_len + ac * f.bound_wid;
-  double hx = ex + 1.0e-6, hy = ey + 1.0e-6;
-  // window in grid coordinates, clamped to the (padded) grid
-  double gx = cx - (double)g.x0, gy = cy - (double)g.y0;
-  double fx0 = fmax(ceil(gx - hx), 0.0), fx1 = fmin(floor(gx + hx), (double)(g.nx - 1));
-  double fy0 = fmax(ceil(gy - hy), 0.0), fy1 = fmin(floor(gy + hy), (double)(g.ny - 1));
-  if (!(fx0 <= fx1) || !(fy0 <= fy1)) return 0;
-  int ix0 = (int)fx0, ix1 = (int)fx1, iy0 = (int)fy0, iy1 = (int)fy1;
-  if (ix1 - ix0 > 20 || iy1 - iy0 > 12)  // footprint larger than the scanline window handles
-    return pp_lattice_scan_exact(cx, cy, c, s, ix0, ix1, iy0, iy1, f, g);
+  const double gx = cx - (double)g.x0, gy = cy - (double)g.y0;
+  if (!f.scan_ok) return pp_lattice_scan_exact(cx, cy, gx, gy, c, s, f, g);
+  // the padding ring is 32 cells wide: from farther out than 26 the footprint reaches no cell
+  if (!(gx >= 26.0 && gx <= (double)(g.nx - 26) && gy >= 26.0 && gy <= (double)(g.ny - 26))) return 0;
+  const double bxf = floor(gx), byf = floor(gy);
+  const int ibx = (int)bxf, iby = (int)byf;
+  const float fx = (float)(gx - bxf), fy = (float)(gy - byf);
+  const int ix0 = ibx - 6, ytop = iby - 6, o = ytop & 3, yb = ytop - o;
+  const float wx = 6.0f + fx, wy = (float)(6 + o) + fy;  // centre in window coordinates
 
-  // inflated rectangle in window coordinates: origin (ix0, yb)
-  const int yb = iy0 & ~3;
-  const double Lo = f.bound_len + PP_SCAN_MARGIN, Wo = f.bound_wid + PP_SCAN_MARGIN;
-  const double sc = (c < 0.0) ? -1.0 : 1.0, ss = (s < 0.0) ? -1.0 : 1.0;
-  const double exo = ac * Lo + as * Wo;                // half-extent in x of the inflated rectangle
-  const double vyo = -sc * Lo * s + ss * Wo * c;       // y of its leftmost vertex, relative to centre
-  const double wx = gx - (double)ix0, wy = gy - (double)yb;
-  const float xL = (float)(wx - exo), yL = (float)(wy + vyo);
-  const float xR1 = (float)(wx + exo + 1.0), yR = (float)(wy - vyo);
-  // edge slopes dx/dy; a zero denominator becomes +-1e-30 (same sign convention as sc/ss)
   const float cf = (float)c, sf = (float)s;
-  const float cden = (fabsf(cf) < 1e-30f) ? (float)(sc * 1e-30) : cf;
-  const float sden = (fabsf(sf) < 1e-30f) ? (float)(ss * 1e-30) : sf;
-  const float m1 = cf / sden, m2 = -sf / cden;
+  const float acf = __builtin_fabsf(cf), asf = __builtin_fabsf(sf);
+  const float exo = __builtin_fmaf(acf, f.scan_lo, asf * f.scan_wo);  // half-extent in x
+  // leftmost vertex relative to the centre: (-exo, vyo), vyo = -sgn(c)*Lo*s + sgn(s)*Wo*c, the
+  // signs taken from the sign BITS so that they agree with the slope denominators below
+  const float s_x = __uint_as_float(__float_as_uint(sf) ^ (__float_as_uint(cf) & 0x80000000u));
+  const float c_x = __uint_as_float(__float_as_uint(cf) ^ (__float_as_uint(sf) & 0x80000000u));
+  const float vyo = __builtin_fmaf(f.scan_wo, c_x, -(f.scan_lo * s_x));
+  PpScan q;
+  q.xL = wx - exo;
+  q.yL = wy + vyo;
+  q.xR1 = wx + exo + 1.0f;
+  q.yR = wy - vyo;
+  // edge slopes dx/dy; a vanishing denominator becomes +-1e-30 with its own sign bit
+  const float sden = (asf < 1e-30f) ? __builtin_copysignf(1e-30f, sf) : sf;
+  const float cden = (acf < 1e-30f) ? __builtin_copysignf(1e-30f, cf) : cf;
+  q.m1 = cf * __builtin_amdgcn_rcpf(sden);
+  q.m2 = -sf * __builtin_amdgcn_rcpf(cden);
+  q.sh = (unsigned)ix0 & 31u;
 
-  const int sh = ix0 & 31;
-  const bool two = (ix1 >> 5) != (ix0 >> 5);
-  const int last_brow = (g.ny - 1) >> 2;
-  unsigned cand = 0;
-  int cand_row = 0;
-#pragma unroll 1
-  for (int br = 0; br < 4; ++br) {
-    const int brow = (yb >> 2) + br;
-    uint4 lb = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
-    if (cand == 0 && brow <= last_brow && (brow << 2) <= iy1) {
-      lb = pp_lattice_block(g, ix0, brow);
-      if (two) rb = pp_lattice_block(g, ix0 + 32, brow);
-    }
-    const unsigned lw[4] = {lb.x, lb.y, lb.z, lb.w};
-    const unsigned rw[4] = {rb.x, rb.y, rb.z, rb.w};
-    unsigned found[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float yr = (float)(br * 4 + r);
-      const float t = yr - yL, t2 = yr - yR;
-      float lo = fmaxf(__builtin_fmaf(t, m1, xL), __builtin_fmaf(t, m2, xL));
-      float hi = fminf(__builtin_fmaf(t2, m1, xR1), __builtin_fmaf(t2, m2, xR1));
-      lo = __builtin_amdgcn_fmed3f(lo, 0.0f, 24.0f);
-      hi = __builtin_amdgcn_fmed3f(hi, 0.0f, 24.0f);
-      const int ilo = (int)ceilf(lo), ihi1 = (int)floorf(hi);  // cells ilo .. ihi1 - 1
-      const int w = max(ihi1 - ilo, 0);
-      const unsigned mask = ((1u << w) - 1u) << ilo;
-      const unsigned bits = __builtin_amdgcn_alignbit(rw[r], lw[r], sh);
-      found[r] = bits & mask;
-    }
-    const unsigned any = found[0] | found[1] | found[2] | found[3];
-    if (any != 0 && cand == 0) {
-      const int r = found[0] ? 0 : found[1] ? 1 : found[2] ? 2 : 3;
-      cand = found[0] ? found[0] : found[1] ? found[1] : found[2] ? found[2] : found[3];
-      cand_row = yb + br * 4 + r;
-    }
+  const bool two = ((ix0 + 12) >> 5) != (ix0 >> 5);
+  const uint4* base = g.blocks + ((size_t)(ix0 >> 5) * (size_t)g.nbrows + (size_t)(yb >> 2));
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  uint4 l1 = base[1], l2 = base[2], r1 = zero, r2 = zero;
+  if (two) {
+    r1 = base[g.nbrows + 1];
+    r2 = base[g.nbrows + 2];
   }
-  if (cand == 0) return 0;
+  unsigned key = 0;
+  key = pp_scan_rows4<4>(q, l1, r1, key);
+  key = pp_scan_rows4<8>(q, l2, r2, key);
+  if (key < 16) {
+    uint4 l0 = base[0], l3 = base[3], r0 = zero, r3 = zero;
+    if (two) {
+      r0 = base[g.nbrows];
+      r3 = base[g.nbrows + 3];
+    }
+    key = pp_scan_rows4<0>(q, l0, r0, key);
+    key = pp_scan_rows4<12>(q, l3, r3, key);
+    if (key < 16) return 0;
+  }
   {
-    const int b = __builtin_ctz(cand);
+    const int b = __builtin_ctz(key >> 4);
     const double ox = (double)((int64_t)(ix0 + b) + g.x0);
-    const double oy = (double)((int64_t)cand_row + g.y0);
+    const double oy = (double)((int64_t)(yb + (int)(key & 15u)) + g.y0);
     if (pp_point_vs_pose(ox, oy, cx, cy, c, s, f) == 1) return PP_F_HIT;
   }
-  return pp_lattice_scan_exact(cx, cy, c, s, ix0, ix1, iy0, iy1, f, g);
+  return pp_lattice_scan_exact(cx, cy, gx, gy, c, s, f, g);
 }
 
 // General obstacle points in unit buckets: every point of the buckets the bounding box touches.

@@ -22,18 +22,22 @@ struct PpFootprint {
   double r2_max;      // largest t with sqrt(t) <= bound_radius (sqrt correctly rounded):
                       // `sqrt(s) <= bound_radius`  <=>  `s <= r2_max`
   double guard;       // guard band for "a different libm could decide otherwise"
+  // scanline raster of the footprint (pp_device.h): half sizes of the inflated rectangle, and
+  // whether the footprint fits the 13-column scan window (bound_radius + inflation <= 6 cells)
+  float scan_lo, scan_wo;
+  int32_t scan_ok;
 };
 
-// Occupancy of an integer-lattice obstacle set, bit-packed and tiled for gather locality.
-//   tile  = 32 x 32 cells = 128 B (one cache line), tiles stored row-major (ty * tiles_x + tx)
-//   block = 32 wide x 4 tall cells = 16 B (one dwordx4 gather); a tile stacks 8 blocks,
-//           block of row y at uint4 index (y >> 2) & 7
-//   word  = one row of a block: bit = column & 31
+// Occupancy of an integer-lattice obstacle set, bit-packed for gather locality.
+//   block = 32 columns x 4 rows = 16 B (one dwordx4 gather): word r = row r, bit = column & 31
+//   strip = the blocks of one 32-column band, stored contiguously bottom to top, so the block
+//           rows a footprint window needs are consecutive uint4 (8 of them per 128-B line)
+//   block of cell (x, y) = blocks[(x >> 5) * nbrows + (y >> 2)]
 // Cell (cx, cy) in lattice coordinates maps to grid coordinates (cx - x0, cy - y0); the grid is
-// padded with one ring of empty tiles so window clamping never needs a per-load bounds test.
+// padded with a ring of 32 empty cells so windows near the rim need no per-load bounds test.
 struct PpLattice {
-  const uint4* tiles;
-  int32_t tiles_x, tiles_y;
+  const uint4* blocks;
+  int32_t nstrips, nbrows;
   int32_t nx, ny;      // cells including padding (multiples of 32)
   int64_t x0, y0;      // lattice coordinate of grid cell (0, 0)
 };

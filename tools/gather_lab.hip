@@ -30,6 +30,18 @@ __global__ void __launch_bounds__(256) k(uint64_t n, const uint4* __restrict__ t
     if (V == 7) { uint2 b = ((const uint2*)t)[(size_t)l0 * 16]; acc |= b.x ^ b.y; }
     if (V == 8) { acc |= ((const uint32_t*)t)[(size_t)l0 * 32]; }
     if (V == 9) { ld(l0, 0); ld(l1, 0); ld(l2, 0); ld(l3, 0); }
+    auto ldn = [&](uint32_t line, int blk) { typedef unsigned v4u __attribute__((ext_vector_type(4))); v4u b = __builtin_nontemporal_load((const v4u*)&t[(size_t)line * 8 + blk]); acc |= b.x ^ b.y ^ b.z ^ b.w; };
+    auto lds1 = [&](uint32_t line, int blk) {
+      const unsigned long long* q = (const unsigned long long*)&t[(size_t)line * 8 + blk];
+      unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc |= (unsigned)(a ^ b) ^ (unsigned)((a ^ b) >> 32); };
+    if (V == 10) ldn(l0, 0);
+    if (V == 11) { ldn(l0, 0); ldn(l1, 0); ldn(l2, 0); ldn(l3, 0); }
+    if (V == 12) { ldn(l0, 0); ldn(l0, 1); ldn(l0, 2); ldn(l0, 3); }
+    if (V == 13) lds1(l0, 0);
+    if (V == 14) { lds1(l0, 0); lds1(l1, 0); lds1(l2, 0); lds1(l3, 0); }
+    if (V == 15) { lds1(l0, 0); lds1(l0, 1); lds1(l0, 2); lds1(l0, 3); }
     out[i] = (uint8_t)acc;
   }
 }
@@ -57,5 +69,11 @@ int main() {
   run(k<5>, "4 x 16B same 64B half-line... (0..3)");
   run(k<6>, "8 x 16B whole line");
   run(k<9>, "4 x 16B different lines");
+  run(k<10>, "nt 1 x 16B");
+  run(k<11>, "nt 4 x 16B different lines");
+  run(k<12>, "nt 4 x 16B same line");
+  run(k<13>, "sc1 (2x8B) 1 block");
+  run(k<14>, "sc1 4 blocks different lines");
+  run(k<15>, "sc1 4 blocks same line");
   return 0;
 }

@@ -13,10 +13,14 @@ k_collision(uint64_t n, const double* __restrict__ x, const double* __restrict__
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     double px = x[i], py = y[i], pyaw = yaw[i];
-    double s, c;
-    sincos(pyaw, &s, &c);
-    unsigned r = LATTICE ? pp_pose_vs_lattice(px, py, c, s, f, lat)
-                         : pp_pose_vs_buckets(px, py, c, s, f, bk);
+    unsigned r;
+    if (LATTICE) {
+      r = pp_pose_yaw_vs_lattice(px, py, pyaw, f, lat);
+    } else {
+      double s, c;
+      sincos(pyaw, &s, &c);
+      r = pp_pose_vs_buckets(px, py, c, s, f, bk);
+    }
     flags[i] = (uint8_t)r;
   }
 }

@@ -120,6 +120,8 @@ PpFootprint pp_make_footprint(const pp_config* conf) {
   const double inflate = 2.5e-4;
   f.scan_lo = std::nextafter((float)(f.bound_len + inflate), 1e30f);
   f.scan_wo = std::nextafter((float)(f.bound_wid + inflate), 1e30f);
+  f.scan_li = std::nextafter((float)(f.bound_len - inflate), -1e30f);
+  f.scan_wi = std::nextafter((float)(f.bound_wid - inflate), -1e30f);
   f.scan_ok = (std::isfinite(f.bound_radius) && f.bound_radius + 2.0 * inflate <= 6.0 &&
                f.bound_len >= 0.0 && f.bound_wid >= 0.0) ? 1 : 0;
   return f;

@@ -90,13 +90,47 @@ __device__ __forceinline__ unsigned pp_lattice_scan_exact(double cx, double cy, 
   return ahit ? (PP_F_HIT | PP_F_AMBIG) : (amb ? PP_F_AMBIG : 0u);
 }
 
-// Four window rows (one block row) of the scanline test; see pp_pose_vs_lattice.  `key` keeps
-// one candidate: (occupied bits under the row mask) << 4 | window row, maximised over rows, so
-// key >= 16 iff some row had a candidate.
+// ---------------------------------------------------------------------------------------------
+// Scanline form of the lattice test, for footprints whose bounding radius is below 6 cells
+// (f.scan_ok).  Everything here is a FILTER around the exact predicate: it may only answer when
+// the exact fp64 predicate (under any libm accurate to a few ulp) provably agrees.
+//
+// The window is the 13 columns floor(gx)-6 .. +6 by the 16 rows of the four block rows covering
+// floor(gy)-6 .. +6, in window coordinates (origin ix0, yb).  Two rectangles around the true
+// footprint rectangle are used, both from fp32 sin/cos (error < 2e-7) and fp32 arithmetic
+// (error < 5e-5 cells at window coordinates below 32):
+//   * inflated by 2.5e-4 on every side (f.scan_lo, f.scan_wo): rasterised row by row, window
+//     row y spanning [lo(y), hi(y)],
+//       lo(y) = xL + max((y - yL) m1, (y - yL) m2),  hi(y) = xR + min((y - yR) m1, (y - yR) m2),
+//     (xL, yL) / (xR, yR) the leftmost / rightmost vertices, m1 = c/s and m2 = -s/c the dx/dy
+//     slopes of the edges.  The row masks cover every cell the exact predicate could accept:
+//     no occupied cell under them => miss.
+//   * deflated by 2.5e-4 (f.scan_li, f.scan_wi): one occupied cell found under the masks is
+//     tested against it; inside => the exact predicate accepts that cell => hit.
+// Anything else (the cell lies in the 5e-4 band around the true edge) is undecided and the
+// caller runs the exact form.  The two central block rows are fetched first; the outer two only
+// by lanes still without a candidate.
+
 struct PpScan {
   float xL, yL, xR1, yR, m1, m2;
   unsigned sh;
 };
+
+// v_cvt_u32_f32 saturates (negative -> 0, huge -> 0xFFFFFFFF); the C++ cast is undefined there.
+__device__ __forceinline__ unsigned pp_cvt_u32_sat(float v) {
+  unsigned r;
+  asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+// ((1 << width) - 1) << offset on the low 5 bits of each operand
+__device__ __forceinline__ unsigned pp_bfm(unsigned width, unsigned offset) {
+  unsigned r;
+  asm("v_bfm_b32 %0, %1, %2" : "=v"(r) : "v"(width), "v"(offset));
+  return r;
+}
+
+// Four window rows (one block row).  `key` keeps one candidate: (occupied bits under the row
+// mask) << 4 | window row, maximised over rows, so key >= 16 iff some row had a candidate.
 template <int J0>
 __device__ __forceinline__ unsigned pp_scan_rows4(const PpScan& q, uint4 lb, uint4 rb, unsigned key) {
   const unsigned lw[4] = {lb.x, lb.y, lb.z, lb.w};
@@ -106,51 +140,60 @@ __device__ __forceinline__ unsigned pp_scan_rows4(const PpScan& q, uint4 lb, uin
   for (int r = 0; r < 4; ++r) {
     const float yr = (float)(J0 + r);
     const float t = yr - q.yL, t2 = yr - q.yR;
-    // lo clamped below at 0 and hi above at 24 by the three-operand max/min
+    // lo clamped below at 0, hi above at 24, by the three-operand max / min
     const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(t, q.m1, q.xL), __builtin_fmaf(t, q.m2, q.xL)), 0.0f);
     const float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaf(t2, q.m1, q.xR1), __builtin_fmaf(t2, q.m2, q.xR1)), 24.0f);
     const float cl = __builtin_ceilf(lo);
     const float wf = __builtin_floorf(hi) - cl;  // cells cl .. floor(hi) - 1 (xR1 carries the +1)
-    const float wc = __builtin_fmaxf(wf, 0.0f);
-    const unsigned w = (unsigned)wc, ilo = (unsigned)__builtin_fminf(cl, 31.0f);
-    const unsigned mask = ((1u << w) - 1u) << ilo;
+    // empty row: wf <= 0 -> width 0 -> mask 0 whatever the offset's low bits are; width <= 24
+    const unsigned mask = pp_bfm(pp_cvt_u32_sat(wf), pp_cvt_u32_sat(cl));
     const unsigned bits = __builtin_amdgcn_alignbit(rw[r], lw[r], q.sh);
     k[r] = ((bits & mask) << 4) | (unsigned)(J0 + r);
   }
   return max(max(key, k[0]), max(max(k[1], k[2]), k[3]));
 }
 
-// Scanline form, for footprints whose bounding radius is below 6 cells (f.scan_ok).  The window
-// is the 13 columns floor(gx)-6 .. +6 by the 16 rows of the four block rows that cover
-// floor(gy)-6 .. +6.  The rectangle, inflated by f.scan_lo/scan_wo - bound (2.5e-4) on every
-// side, is rasterised row by row in fp32: window row y spans [lo(y), hi(y)] with
-//   lo(y) = xL + max((y - yL) * m1, (y - yL) * m2),  hi(y) = xR + min((y - yR) * m1, (y - yR) * m2)
-// where (xL, yL) / (xR, yR) are the leftmost / rightmost vertices and m1 = c/s, m2 = -s/c the
-// dx/dy slopes of the edges.  fp32 evaluation errors (< 5e-5 cells at window coordinates below
-// 32) are far inside the inflation, so the row masks cover every cell the exact predicate could
-// accept: no occupied cell under the masks => miss.  One occupied cell under a mask is put to
-// the exact fp64 predicate; a clear hit settles the pose, anything else (the cell sits in the
-// thin band between the true and the inflated rectangle) falls back to the exhaustive form.
-// The two central block rows are fetched first; the outer two only by lanes still undecided.
-__device__ __forceinline__ unsigned pp_pose_vs_lattice(double x, double y, double c, double s,
-                                                       const PpFootprint& f, const PpLattice& g) {
-  double cx, cy;
-  pp_footprint_centre(x, y, c, s, f, cx, cy);
-  if (!(fabs(cx) < 1.0e300) || !(fabs(cy) < 1.0e300)) return PP_F_NONFINITE;
-  const double gx = cx - (double)g.x0, gy = cy - (double)g.y0;
-  if (!f.scan_ok) return pp_lattice_scan_exact(cx, cy, gx, gy, c, s, f, g);
+// sin and cos of yaw to fp32 accuracy (absolute error < 2e-7) for |yaw| < 1e8: one fp64
+// reduction step to [-pi/4, pi/4], then fp32 polynomials.  Returns false outside that range.
+__device__ __forceinline__ bool pp_sincos_f32(double yaw, float& sf, float& cf) {
+  if (!(fabs(yaw) < 1.0e8)) return false;
+  const double kd = rint(yaw * 0.63661977236758134308);       // 2/pi
+  const double r = __builtin_fma(-kd, 1.57079632679489661923, yaw);
+  const int q = (int)kd;
+  const float x = (float)r, z = x * x;
+  float ps = __builtin_fmaf(z, 2.7557319e-6f, -1.9841270e-4f);
+  ps = __builtin_fmaf(z, ps, 8.3333333e-3f);
+  ps = __builtin_fmaf(z, ps, -1.6666667e-1f);
+  const float sn = __builtin_fmaf(x * z, ps, x);
+  float pc = __builtin_fmaf(z, 2.4801587e-5f, -1.3888889e-3f);
+  pc = __builtin_fmaf(z, pc, 4.1666668e-2f);
+  pc = __builtin_fmaf(z, pc, -0.5f);
+  const float cs = __builtin_fmaf(z, pc, 1.0f);
+  const float a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
+  sf = __uint_as_float(__float_as_uint(a) ^ (((unsigned)q & 2u) << 30));
+  cf = __uint_as_float(__float_as_uint(b) ^ (((unsigned)(q + 1) & 2u) << 30));
+  return true;
+}
+
+// Result of the filter: 0 = miss, 1 = hit, 2 = undecided.
+__device__ __forceinline__ int pp_lattice_filter(double x, double y, float cf, float sf,
+                                                 const PpFootprint& f, const PpLattice& g) {
+  // footprint centre from the fp32 direction: off by < 1e-6, inside the filter's margins
+  const double gx = (x + f.cp2center * (double)cf) - (double)g.x0;
+  const double gy = (y + f.cp2center * (double)sf) - (double)g.y0;
   // the padding ring is 32 cells wide: from farther out than 26 the footprint reaches no cell
-  if (!(gx >= 26.0 && gx <= (double)(g.nx - 26) && gy >= 26.0 && gy <= (double)(g.ny - 26))) return 0;
+  // (NaN and infinities fail the comparison and are left to the exact form)
+  const bool inside = gx >= 26.0 && gx <= (double)(g.nx - 26) && gy >= 26.0 && gy <= (double)(g.ny - 26);
+  if (!inside) return (fabs(gx) < 1.0e300 && fabs(gy) < 1.0e300) ? 0 : 2;
   const double bxf = floor(gx), byf = floor(gy);
   const int ibx = (int)bxf, iby = (int)byf;
   const float fx = (float)(gx - bxf), fy = (float)(gy - byf);
   const int ix0 = ibx - 6, ytop = iby - 6, o = ytop & 3, yb = ytop - o;
   const float wx = 6.0f + fx, wy = (float)(6 + o) + fy;  // centre in window coordinates
 
-  const float cf = (float)c, sf = (float)s;
   const float acf = __builtin_fabsf(cf), asf = __builtin_fabsf(sf);
   const float exo = __builtin_fmaf(acf, f.scan_lo, asf * f.scan_wo);  // half-extent in x
-  // leftmost vertex relative to the centre: (-exo, vyo), vyo = -sgn(c)*Lo*s + sgn(s)*Wo*c, the
+  // leftmost vertex relative to the centre: (-exo, vyo), vyo = -sgn(c) Lo s + sgn(s) Wo c, the
   // signs taken from the sign BITS so that they agree with the slope denominators below
   const float s_x = __uint_as_float(__float_as_uint(sf) ^ (__float_as_uint(cf) & 0x80000000u));
   const float c_x = __uint_as_float(__float_as_uint(cf) ^ (__float_as_uint(sf) & 0x80000000u));
@@ -188,13 +231,42 @@ __device__ __forceinline__ unsigned pp_pose_vs_lattice(double x, double y, doubl
     key = pp_scan_rows4<12>(q, l3, r3, key);
     if (key < 16) return 0;
   }
-  {
-    const int b = __builtin_ctz(key >> 4);
-    const double ox = (double)((int64_t)(ix0 + b) + g.x0);
-    const double oy = (double)((int64_t)(yb + (int)(key & 15u)) + g.y0);
-    if (pp_point_vs_pose(ox, oy, cx, cy, c, s, f) == 1) return PP_F_HIT;
+  // one candidate cell against the deflated rectangle
+  const float dx = (float)__builtin_ctz(key >> 4) - wx, dy = (float)(key & 15u) - wy;
+  const float u = __builtin_fmaf(dx, cf, dy * sf), v = __builtin_fmaf(dy, cf, -(dx * sf));
+  return (__builtin_fabsf(u) < f.scan_li && __builtin_fabsf(v) < f.scan_wi) ? 1 : 2;
+}
+
+// Exact form from the pose and its fp64 direction.
+__device__ __forceinline__ unsigned pp_lattice_exact(double x, double y, double c, double s,
+                                                     const PpFootprint& f, const PpLattice& g) {
+  double cx, cy;
+  pp_footprint_centre(x, y, c, s, f, cx, cy);
+  if (!(fabs(cx) < 1.0e300) || !(fabs(cy) < 1.0e300)) return PP_F_NONFINITE;
+  return pp_lattice_scan_exact(cx, cy, cx - (double)g.x0, cy - (double)g.y0, c, s, f, g);
+}
+
+// Pose with a known fp64 direction (the rollout and trajectory kernels have it already).
+__device__ __forceinline__ unsigned pp_pose_vs_lattice(double x, double y, double c, double s,
+                                                       const PpFootprint& f, const PpLattice& g) {
+  if (f.scan_ok) {
+    const int r = pp_lattice_filter(x, y, (float)c, (float)s, f, g);
+    if (r < 2) return r ? PP_F_HIT : 0u;
   }
-  return pp_lattice_scan_exact(cx, cy, gx, gy, c, s, f, g);
+  return pp_lattice_exact(x, y, c, s, f, g);
+}
+
+// Pose given by its yaw: fp32 direction for the filter, fp64 sin/cos only when undecided.
+__device__ __forceinline__ unsigned pp_pose_yaw_vs_lattice(double x, double y, double yaw,
+                                                           const PpFootprint& f, const PpLattice& g) {
+  float sf, cf;
+  if (f.scan_ok && pp_sincos_f32(yaw, sf, cf)) {
+    const int r = pp_lattice_filter(x, y, cf, sf, f, g);
+    if (r < 2) return r ? PP_F_HIT : 0u;
+  }
+  double s, c;
+  sincos(yaw, &s, &c);
+  return pp_lattice_exact(x, y, c, s, f, g);
 }
 
 // General obstacle points in unit buckets: every point of the buckets the bounding box touches.

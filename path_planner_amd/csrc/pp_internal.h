@@ -24,7 +24,8 @@ struct PpFootprint {
   double guard;       // guard band for "a different libm could decide otherwise"
   // scanline raster of the footprint (pp_device.h): half sizes of the inflated rectangle, and
   // whether the footprint fits the 13-column scan window (bound_radius + inflation <= 6 cells)
-  float scan_lo, scan_wo;
+  // (scan_lo, scan_wo) and of the deflated one (scan_li, scan_wi), rounded outward / inward
+  float scan_lo, scan_wo, scan_li, scan_wi;
   int32_t scan_ok;
 };
 

@@ -146,8 +146,8 @@ def load_library(path=None):
         "pp_wavefront_dev": (C.c_int32, [vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_uint64,
                                          vp, u64]),
         "pp_wavefront_slab_dev": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
-                                              vp, vp, C.c_int32, C.c_uint64, C.c_uint64, i32, i32,
-                                              u64]),
+                                              vp, vp, C.c_int32, C.c_uint64, C.c_uint64, vp, vp,
+                                              i32, i32, u64]),
         "pp_rs_batch": (C.c_int32, [vp, C.c_uint64, d, d, d, d, d, d, C.c_double, i32, i32,
                                     C.POINTER(RsWord), u8]),
         "pp_rs_batch_dev": (C.c_int32, [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_double, vp, vp,

@@ -2,10 +2,6 @@
 #include "pp_internal.h"
 #define STUB { return PP_ERR_UNSUPPORTED; }
 extern "C" {
-int32_t pp_heuristic(pp_ctx*, const pp_map*, double, double, double, double, double*, uint64_t, uint64_t*) STUB
-int32_t pp_obsmap(pp_ctx*, const pp_map*, double, double, uint8_t*, uint64_t, uint64_t*) STUB
-int32_t pp_wavefront_dev(pp_ctx*, uint64_t, uint64_t, const uint8_t*, uint64_t, uint64_t, double*, uint64_t*) STUB
-int32_t pp_wavefront_slab_dev(pp_ctx*, uint64_t, uint64_t, uint64_t, uint64_t, const uint8_t*, double*, int32_t, uint64_t, uint64_t, int32_t*, int32_t*, uint64_t*) STUB
 int32_t pp_rs_batch(pp_ctx*, uint64_t, const double*, const double*, const double*, const double*, const double*, const double*, double, int32_t*, int32_t*, pp_rs_word*, uint8_t*) STUB
 int32_t pp_rs_batch_dev(pp_ctx*, uint64_t, const double*, const double*, const double*, const double*, const double*, const double*, double, int32_t*, int32_t*, pp_rs_word*, uint8_t*) STUB
 int32_t pp_rs_all_paths(pp_ctx*, double, double, double, double, double, double, double, double, int32_t*, pp_rs_word*, uint64_t*, double*, double*, double*, int64_t*, uint64_t) STUB

@@ -1,0 +1,152 @@
+"""Parity of the obstacle-raster and wavefront kernels against the CPU oracle (bit-exact)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from path_planner_amd import _abi as A
+from path_planner_amd import api
+from path_planner_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def same_grid(got, exp):
+    assert got.shape == exp.shape
+    assert (np.isinf(got) == np.isinf(exp)).all()
+    fin = np.isfinite(exp)
+    assert (got[fin] == exp[fin]).all()  # bit-exact
+
+
+def test_heuristic_golden(ctx):
+    ox, oy = W.demo_obstacles()
+    for h in json.load(open(os.path.join(G, "heuristic.json"))):
+        hox, hoy = (h["ox"], h["oy"]) if "ox" in h else (ox, oy)
+        m = api.ObstacleMap(ctx, hox, hoy)
+        obs, dims = api.calc_obsmap(ctx, m, h["reso"], h["rr"])
+        assert dims.tolist() == h["dims"] and obs.tolist() == h["obsmap"]
+        hm, dims = api.calc_holonomic_heuristic_with_obstacle(ctx, m, h["gx"], h["gy"], h["reso"], h["rr"])
+        exp = np.array([[math.inf if v == "inf" else v for v in row] for row in h["hmap"]])
+        same_grid(hm, exp)
+
+
+def test_heuristic_demo_goal_rust_rounding(ctx):
+    # 45/2 = 22.5 rounds half away from zero to cell 23 (the Python twin would pick 22)
+    ox, oy = W.demo_obstacles()
+    m = api.ObstacleMap(ctx, ox, oy)
+    hm, dims = api.calc_holonomic_heuristic_with_obstacle(ctx, m, 45.0, 20.0, 2.0, 1.0)
+    st, exp, edims = O.heuristic(ox, oy, 45.0, 20.0, 2.0, 1.0)
+    assert st == 0 and dims.tolist() == edims.tolist()
+    same_grid(hm, exp)
+    assert hm[23, 10] == 0.0 and np.isfinite(hm).sum() == 302
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_obsmap_and_heuristic_random_points_vs_oracle(ctx, seed):
+    rng = np.random.default_rng(seed)
+    n = 600
+    ox, oy = rng.uniform(0, 90, n), rng.uniform(0, 70, n)   # non-lattice obstacle points
+    ox[:4], oy[:4] = [0, 90, 0, 90], [0, 0, 70, 70]
+    reso, rr = [(1.0, 0.7), (2.0, 1.0), (0.5, 1.3)][seed - 1]
+    m = api.ObstacleMap(ctx, ox, oy)
+    obs, dims = api.calc_obsmap(ctx, m, reso, rr)
+    st, eobs, edims = O.obsmap(ox, oy, reso, rr, 1)
+    assert dims.tolist() == edims.tolist() and (obs == eobs).all()
+    gx, gy = 45.3, 33.1
+    hm, _ = api.calc_holonomic_heuristic_with_obstacle(ctx, m, gx, gy, reso, rr)
+    st, exp, _ = O.heuristic(ox, oy, gx, gy, reso, rr)
+    assert st == 0
+    same_grid(hm, exp)
+
+
+def test_obsmap_exact_threshold_cases(ctx):
+    """Distances that land exactly on (or one ulp around) rr/reso: the decision must be the
+    one a correctly rounded hypot gives (glibc's on the host)."""
+    pts = [(10.0, 10.0), (13.0, 14.0), (20.5, 10.0), (30.0, 30.0)]
+    ox = np.array([0.0, 40.0] + [p[0] for p in pts])
+    oy = np.array([0.0, 40.0] + [p[1] for p in pts])
+    m = api.ObstacleMap(ctx, ox, oy)
+    for rr in (5.0, np.nextafter(5.0, 0), np.nextafter(5.0, 9), math.hypot(3.0, 4.0), 0.5, 2.5,
+               math.hypot(1.0, 2.0), np.nextafter(math.hypot(1.0, 2.0), 0), math.sqrt(2.0),
+               np.nextafter(math.sqrt(2.0), 0), np.nextafter(math.sqrt(2.0), 9)):
+        obs, dims = api.calc_obsmap(ctx, m, 1.0, float(rr))
+        st, eobs, _ = O.obsmap(ox, oy, 1.0, float(rr), 0)
+        assert (obs == eobs).all(), rr
+
+
+@pytest.mark.parametrize("n,p,kind", [(96, 0.2, "bernoulli"), (300, 0.3, "bernoulli"),
+                                      (257, 0.0, "walls"), (512, 0.15, "bernoulli")])
+def test_wavefront_vs_oracle(ctx, n, p, kind):
+    import torch
+    obs, gx, gy = W.wavefront_obsmap(n, p, kind=kind)
+    d_obs = torch.from_numpy(obs).cuda()
+    cost = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    iters = api.wavefront_dev(ctx, d_obs, gx, gy, cost)
+    ctx.synchronize()
+    st, exp = O.wavefront(obs, gx, gy)
+    assert st == 0
+    same_grid(cost.cpu().numpy(), exp)
+    assert iters > 0
+
+
+def test_wavefront_goal_on_obstacle_and_border_and_errors(ctx):
+    import torch
+    obs, gx, gy = W.wavefront_obsmap(64, 0.2)
+    obs[10, 10] = 1
+    for (x, y) in [(10, 10), (0, 5), (63, 63)]:
+        d_obs = torch.from_numpy(obs).cuda()
+        cost = torch.empty((64, 64), dtype=torch.float64, device="cuda")
+        api.wavefront_dev(ctx, d_obs, x, y, cost)
+        ctx.synchronize()
+        st, exp = O.wavefront(obs, x, y)
+        same_grid(cost.cpu().numpy(), exp)
+    with pytest.raises(api.PlannerError) as e:
+        api.wavefront_dev(ctx, d_obs, 64, 3, cost)
+    assert e.value.status == A.PP_ERR_BOUNDS
+
+
+def test_wavefront_rectangular_and_fixpoint_property_large(ctx):
+    """2048 x 1024 grid: too slow for the oracle in a unit test, so check the defining property
+    instead -- the result is a fixpoint of the relaxation and 0 at the goal."""
+    import torch
+    xw, yw = 2048, 1024
+    u = W.uniform01(77, 0, xw * yw).reshape(xw, yw)
+    obs = (u < 0.25).astype(np.uint8)
+    obs[0, :] = obs[-1, :] = 1
+    obs[:, 0] = obs[:, -1] = 1
+    gx, gy = 1000, 500
+    obs[gx, gy] = 0
+    d_obs = torch.from_numpy(obs).cuda()
+    cost = torch.empty((xw, yw), dtype=torch.float64, device="cuda")
+    api.wavefront_dev(ctx, d_obs, gx, gy, cost)
+    ctx.synchronize()
+    d = cost
+    assert float(d[gx, gy]) == 0.0
+    inf = float("inf")
+    valid = torch.zeros((xw, yw), dtype=torch.bool, device="cuda")
+    valid[1:, 1:] = True
+    valid &= d_obs == 0
+    p = torch.nn.functional.pad(d, (1, 1, 1, 1), value=inf)
+    best = torch.full_like(d, inf)
+    s2 = math.hypot(1.0, 1.0)
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            if dx == 0 and dy == 0:
+                continue
+            w = 1.0 if dx == 0 or dy == 0 else s2
+            best = torch.minimum(best, p[1 + dx:1 + dx + xw, 1 + dy:1 + dy + yw] + w)
+    best = torch.where(valid, best, torch.full_like(best, inf))
+    best[gx, gy] = 0.0
+    assert bool(((best == d) | (torch.isinf(best) & torch.isinf(d))).all())
+    assert int(torch.isfinite(d).sum()) > xw * yw // 2

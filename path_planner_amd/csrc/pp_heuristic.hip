@@ -132,30 +132,80 @@ __device__ inline void wave_push(const WaveQueues& q, uint32_t cell, double c) {
   atomicMax(&q.status[0], b);
 }
 
+// Relax the 8 neighbours of one final cell.  The loads, the atomic mins and the queue-slot
+// reservations are each issued as a group so their latencies overlap; a cell in bucket k only
+// ever pushes into buckets k+1 and k+2 (1 <= w < 1.5), so two reservations per lane suffice.
 __device__ inline void wave_expand(const WaveGrid& g, const WaveQueues& q, uint32_t cell, double c,
-                                   double diag) {
-  uint32_t lx = cell / g.yw, y = cell - lx * g.yw;
+                                   double diag, uint32_t k) {
+  const uint32_t lx = cell / g.yw, y = cell - lx * g.yw;
+  uint32_t ncell[8];
+  double nc[8];
+  bool ok[8];
+  uint8_t ob[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int j = 0; j < 8; ++j) {
     // astar.rs:297-308
-    const int dx = (k == 0 || k == 1 || k == 7) ? -1 : ((k >= 3 && k <= 5) ? 1 : 0);
-    const int dy = (k >= 1 && k <= 3) ? 1 : ((k >= 5) ? -1 : 0);
-    int64_t nlx = (int64_t)lx + dx;
-    int64_t ny = (int64_t)y + dy;
-    if (nlx < (int64_t)g.tgt_lo || nlx >= (int64_t)g.tgt_hi) continue;
-    int64_t ngx = nlx + g.gx_off;
-    if (ngx <= 0 || ngx >= g.xw || ny <= 0 || ny >= (int64_t)g.yw) continue;  // check_node :200-204
-    uint32_t ncell = (uint32_t)nlx * g.yw + (uint32_t)ny;
-    if (g.obs[ncell]) continue;                                               // :206-208
-    double nc = c + ((dx != 0 && dy != 0) ? diag : 1.0);
-    unsigned long long nb = (unsigned long long)__double_as_longlong(nc);
-    unsigned long long old = atomicMin((unsigned long long*)&g.cost[ncell], nb);
-    if (nb < old) {
-      wave_push(q, ncell, nc);
-      if ((uint32_t)nlx == g.tgt_lo) q.status[2] = 1;
-      if ((uint32_t)nlx + 1 == g.tgt_hi) q.status[3] = 1;
+    const int dx = (j == 0 || j == 1 || j == 7) ? -1 : ((j >= 3 && j <= 5) ? 1 : 0);
+    const int dy = (j >= 1 && j <= 3) ? 1 : ((j >= 5) ? -1 : 0);
+    const int64_t nlx = (int64_t)lx + dx, ny = (int64_t)y + dy, ngx = nlx + g.gx_off;
+    // owned column, and check_node's bounds (astar.rs:200-204)
+    ok[j] = nlx >= (int64_t)g.tgt_lo && nlx < (int64_t)g.tgt_hi && ngx > 0 && ngx < g.xw && ny > 0 &&
+            ny < (int64_t)g.yw;
+    ncell[j] = ok[j] ? (uint32_t)nlx * g.yw + (uint32_t)ny : cell;
+    nc[j] = c + ((dx != 0 && dy != 0) ? diag : 1.0);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ob[j] = g.obs[ncell[j]];
+  unsigned long long old[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ok[j] = ok[j] && ob[j] == 0;  // astar.rs:206-208
+    const unsigned long long nb = (unsigned long long)__double_as_longlong(nc[j]);
+    old[j] = ok[j] ? atomicMin((unsigned long long*)&g.cost[ncell[j]], nb) : 0ull;
+  }
+  uint32_t n1 = 0, n2 = 0;
+  const double k2 = (double)k + 2.0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ok[j] = ok[j] && (unsigned long long)__double_as_longlong(nc[j]) < old[j];
+    if (ok[j]) {
+      if (nc[j] < k2) ++n1; else ++n2;
     }
   }
+  if (n1 + n2 == 0) return;
+  const uint32_t b1 = k + 1, b2 = k + 2;
+  if (b2 >= q.nbuckets) {
+    atomicOr(&q.status[1], 2u);
+    return;
+  }
+  uint32_t s1 = n1 ? atomicAdd(&q.count[b1], n1) : 0u;
+  uint32_t s2 = n2 ? atomicAdd(&q.count[b2], n2) : 0u;
+  if ((n1 && s1 + n1 > q.cap) || (n2 && s2 + n2 > q.cap)) {
+    atomicOr(&q.status[1], 1u);
+    return;
+  }
+  uint32_t* c1 = q.cell[b1 % 3];
+  uint32_t* c2 = q.cell[b2 % 3];
+  double* v1 = q.qcost[b1 % 3];
+  double* v2 = q.qcost[b2 % 3];
+  bool edge_lo = false, edge_hi = false;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (!ok[j]) continue;
+    if (nc[j] < k2) {
+      c1[s1] = ncell[j];
+      v1[s1++] = nc[j];
+    } else {
+      c2[s2] = ncell[j];
+      v2[s2++] = nc[j];
+    }
+    const uint32_t nlx = ncell[j] / g.yw;
+    edge_lo |= nlx == g.tgt_lo;
+    edge_hi |= nlx + 1 == g.tgt_hi;
+  }
+  atomicMax(&q.status[0], n2 ? b2 : b1);
+  if (edge_lo) q.status[2] = 1;
+  if (edge_hi) q.status[3] = 1;
 }
 
 __global__ void __launch_bounds__(256)
@@ -178,7 +228,7 @@ k_wave_step(WaveGrid g, WaveQueues q, uint32_t k, double diag) {
       c = g.cost[cell];
       if (!(c >= (double)k && c < (double)k + 1.0)) continue;
     }
-    wave_expand(g, q, cell, c, diag);
+    wave_expand(g, q, cell, c, diag, k);
   }
 }
 

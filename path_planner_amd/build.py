@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libpp_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-bitwise-instead-of-logical"]
 
 
 def _sources():

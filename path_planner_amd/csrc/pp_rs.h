@@ -1,0 +1,45 @@
+// pp_rs.h -- device-side records of the Reeds-Shepp kernels, shared with the planner.
+#ifndef PP_RS_H_
+#define PP_RS_H_
+
+#include "pp_internal.h"
+
+// One accepted word, lengths in normalised (curvature) units, stored at its generation index.
+struct PpRsCand {
+  double len[5];
+  double total;
+  uint32_t word;  // letters packed 4 bits each: 1 L, 2 S, 3 R
+  int32_t nseg;
+};
+
+struct PpRsPair {
+  uint64_t accepted;  // bit i: candidate with generation index i became a path
+  uint32_t flags;     // bit1 guard-band decision, bit2 degenerate pair (the :157 assert)
+  int32_t n_paths;
+};
+
+// Result of one analytic-expansion shot.
+struct PpShotOut {
+  double cost;       // calc_rs_path_cost of the accepted path
+  int32_t path_idx;  // index in calc_all_paths order, -1 = None
+  int32_t gen;       // generation index of that path
+  int32_t n_paths;
+  uint32_t flags;    // bit0 found, bit1 guard band, bit2 degenerate, bit3 NaN cost, bit4 non-finite pose
+};
+
+struct PpCostParams {
+  double backward_cost, gear_cost, steer_angle_cost, steer_change_cost, max_steer;
+};
+
+// d_q: six arrays of n doubles back to back (sx, sy, syaw, gx, gy, gyaw).
+void pp_rs_words_launch(pp_ctx* ctx, uint64_t n, const double* d_q, double maxc, PpRsCand* d_cands,
+                        PpRsPair* d_pairs);
+void pp_rs_shot_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, uint32_t n,
+                       const double* d_q, double maxc, const PpRsCand* d_cands,
+                       const PpRsPair* d_pairs, PpShotOut* d_out);
+int32_t pp_rs_single(pp_ctx* ctx, const double q[6], double maxc, double step_size, int only_rank,
+                     int32_t* n_paths, pp_rs_word* words, uint64_t* traj_off, double* traj_x,
+                     double* traj_y, double* traj_yaw, int64_t* traj_dir, uint64_t traj_cap,
+                     uint32_t* flags_out);
+
+#endif

@@ -1,0 +1,718 @@
+// pp_rs.hip -- Reeds-Shepp kernels: word generation + optimal-path selection for batches of
+// pairs (generate_path / calc_optimal_path, reeds_shepp.rs:60-85, :707-725), trajectory sampling
+// (generate_local_course / interpolate / global transform, :87-128, :581-705) and the
+// analytic-expansion shot of the planner (hybrid_astar.rs:380-415, :450-489).
+#include <algorithm>
+
+#include "pp_device.h"
+#include "pp_rs.h"
+#include "pp_rs_device.h"
+
+namespace {
+
+// ------------------------------------------------------------------ K3: words, one lane per pair
+
+struct BestSink {
+  double maxc;
+  double best_total = 0.0;
+  int best_gen = -1;
+  uint32_t best_word = 0;
+  int best_n = 0;
+  bool near_tie = false;  // another word's total lies within the guard band of the best one
+  double best_len[5] = {0, 0, 0, 0, 0};
+  __device__ __forceinline__ void operator()(int gen, uint32_t word, int n, const double* len, double total) {
+    double td = total / maxc;  // the selection compares de-normalised totals (:125, :77)
+    // min total, ties -> the later path in generation order (fold with `<=`, :72-82)
+    bool take = best_gen < 0 || td < best_total || (td == best_total && gen > best_gen);
+    if (best_gen >= 0) {
+      double eps = PP_RS_GUARD * fmax(td, best_total);
+      if (fabs(td - best_total) <= eps) near_tie = true;   // mirror-image words tie mathematically
+      else if (take) near_tie = false;                     // clearly better: earlier ties are moot
+    }
+    if (take) {
+      best_total = td;
+      best_gen = gen;
+      best_word = word;
+      best_n = n;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) best_len[i] = len[i];
+    }
+  }
+};
+
+__device__ inline void write_word(pp_rs_word* o, uint32_t word, int n, const double* len_norm,
+                                  double total_denorm, double maxc) {
+  for (int i = 0; i < 5; ++i) {
+    o->lengths[i] = i < n ? len_norm[i] / maxc : 0.0;  // :124
+    o->ctypes[i] = i < n ? pp_word_letter(word, i) : 0;
+  }
+  o->total_length = total_denorm;
+  o->nseg = (uint8_t)n;
+  o->pad_[0] = o->pad_[1] = 0;
+}
+
+__global__ void __launch_bounds__(128)
+k_rs_batch(uint64_t n, const double* __restrict__ sx, const double* __restrict__ sy,
+           const double* __restrict__ syaw, const double* __restrict__ gx,
+           const double* __restrict__ gy, const double* __restrict__ gyaw, double maxc,
+           int32_t* __restrict__ n_paths, int32_t* __restrict__ best_idx,
+           pp_rs_word* __restrict__ best, uint8_t* __restrict__ flags) {
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    PpRsState S;
+    BestSink sink;
+    sink.maxc = maxc;
+    pp_rs_generate(sx[i], sy[i], syaw[i], gx[i], gy[i], gyaw[i], maxc, S, sink);
+    int np = __popcll(S.accepted);
+    if (S.degenerate) {  // the reference panics inside generate_path: no paths reported
+      n_paths[i] = 0;
+      best_idx[i] = -1;
+      pp_rs_word z{};
+      best[i] = z;
+      flags[i] = 1 | (S.A.amb ? 2 : 0);
+      continue;
+    }
+    n_paths[i] = np;
+    if (np == 0) {
+      best_idx[i] = -1;
+      pp_rs_word z{};
+      best[i] = z;
+    } else {
+      best_idx[i] = __popcll(S.accepted & ((1ull << sink.best_gen) - 1ull));
+      write_word(&best[i], sink.best_word, sink.best_n, sink.best_len, sink.best_total, maxc);
+    }
+    flags[i] = (S.A.amb || sink.near_tie) ? 2 : 0;
+  }
+}
+
+// ------------------------------------------------------------------ all words of a pair
+
+struct AllSink {
+  PpRsCand* slots;  // 46 entries indexed by generation index
+  __device__ __forceinline__ void operator()(int gen, uint32_t word, int n, const double* len, double total) {
+    PpRsCand c;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) c.len[i] = len[i];
+    c.total = total;
+    c.word = word;
+    c.nseg = n;
+    slots[gen] = c;
+  }
+};
+
+__global__ void __launch_bounds__(128)
+k_rs_words(uint64_t n, const double* __restrict__ sx, const double* __restrict__ sy,
+           const double* __restrict__ syaw, const double* __restrict__ gx,
+           const double* __restrict__ gy, const double* __restrict__ gyaw, double maxc,
+           PpRsCand* __restrict__ cands, PpRsPair* __restrict__ pairs) {
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    PpRsState S;
+    AllSink sink{cands + i * PP_RS_MAX_PATHS};
+    pp_rs_generate(sx[i], sy[i], syaw[i], gx[i], gy[i], gyaw[i], maxc, S, sink);
+    PpRsPair p;
+    p.accepted = S.degenerate ? 0ull : S.accepted;
+    p.flags = (S.degenerate ? 4u : 0u) | (S.A.amb ? 2u : 0u);
+    p.n_paths = __popcll(p.accepted);
+    pairs[i] = p;
+  }
+}
+
+// ------------------------------------------------------------------ local course bookkeeping
+
+// One segment of one path, as generate_local_course walks it (:601-655).
+struct Seg {
+  double pd0, d, l;        // first sample offset, signed step, segment length (normalised)
+  double ox, oy, oyaw;     // segment origin = end of the previous segment (start frame, metres)
+  double co, so;           // cos / sin of oyaw
+  int32_t first;           // trajectory index of the first sample
+  int32_t n;               // number of samples (loop iterations of :625-640)
+  int32_t type;            // 1 L, 2 S, 3 R
+  int32_t pad_;
+};
+struct PathPlan {
+  Seg seg[5];
+  int32_t nseg;
+  int32_t npts;            // after the trailing-zero trim (:656-661)
+  int32_t dir0;
+  uint32_t amb;
+};
+
+// interpolate, :665-705, with the segment origin's cos/sin precomputed.
+__device__ inline void interp(const Seg& s, double pd, double maxc, double& px, double& py,
+                              double& pyaw, int& dir) {
+  if (s.type == 2) {
+    px = s.ox + pd / maxc * s.co;
+    py = s.oy + pd / maxc * s.so;
+    pyaw = s.oyaw;
+  } else {
+    double sl, cl;
+    sincos(pd, &sl, &cl);
+    double ldx = sl / maxc;
+    double ldy = (s.type == 1) ? (1.0 - cl) / maxc : -(1.0 - cl) / maxc;
+    // cos(-oyaw) = co, sin(-oyaw) = -so
+    double gdx = s.co * ldx + (-s.so) * ldy;
+    double gdy = s.so * ldx + s.co * ldy;
+    px = s.ox + gdx;
+    py = s.oy + gdy;
+    pyaw = (s.type == 1) ? s.oyaw + pd : s.oyaw - pd;
+  }
+  dir = pd > 0.0 ? 1 : -1;
+}
+
+// Index bookkeeping of generate_local_course without walking the samples: the loop
+// `while |pd| <= |l| { pd += d }` runs n = floor((l - pd0)/d) + 1 times when it runs at all.
+// The count is verified against the loop condition at both ends; a verification inside the
+// guard band is reported.
+__device__ inline void plan_path(const PpRsCand& c, double maxc, double step, PathPlan& P) {
+  P.nseg = c.nseg;
+  P.dir0 = c.len[0] > 0.0 ? 1 : -1;
+  P.amb = 0;
+  double ll = 0.0;
+  double ox = 0.0, oy = 0.0, oyaw = 0.0;
+  int32_t ind = 1;
+  for (int i = 0; i < c.nseg; ++i) {
+    Seg& s = P.seg[i];
+    double l = c.len[i];
+    double d = l > 0.0 ? step : -step;
+    s.type = (int32_t)((c.word >> (4 * i)) & 15u);
+    s.l = l;
+    s.d = d;
+    s.ox = ox;
+    s.oy = oy;
+    s.oyaw = oyaw;
+    sincos(oyaw, &s.so, &s.co);
+    double pd0;
+    if (i >= 1 && c.len[i - 1] * c.len[i] > 0.)
+      pd0 = -d - ll;
+    else
+      pd0 = d - ll;
+    s.pd0 = pd0;
+    int32_t first = ind - 1 + 1;  // ind -= 1, then the first write goes to ind + 1
+    s.first = first;
+    int32_t n = 0;
+    const double al = fabs(l);
+    if (fabs(pd0) <= al) {
+      double mm = floor((l - pd0) / d);
+      if (!(mm >= 0.0)) mm = 0.0;
+      if (mm > 1.0e7) mm = 1.0e7;
+      while (fabs(pd0 + (mm + 1.0) * d) <= al) mm += 1.0;
+      while (mm > 0.0 && fabs(pd0 + mm * d) > al) mm -= 1.0;
+      n = (int32_t)mm + 1;
+      if (fabs(fabs(pd0 + mm * d) - al) < PP_RS_GUARD || fabs(fabs(pd0 + (mm + 1.0) * d) - al) < PP_RS_GUARD)
+        P.amb = 1;
+    } else if (fabs(fabs(pd0) - al) < PP_RS_GUARD) {
+      P.amb = 1;
+    }
+    s.n = n;
+    double pd_exit = pd0 + (double)n * d;
+    ll = l - pd_exit - d;
+    ind = first + n;  // index of the segment's end point
+    // the segment's end point is the next segment's origin
+    double ex, ey, eyaw;
+    int dir;
+    interp(s, l, maxc, ex, ey, eyaw, dir);
+    ox = ex;
+    oy = ey;
+    oyaw = eyaw;
+  }
+  P.npts = ind + 1;
+}
+
+// Trajectory point j of a planned path in the start frame.
+__device__ inline void local_point(const PathPlan& P, int j, double maxc, double& px, double& py,
+                                   double& pyaw, int& dir) {
+  if (j == 0) {
+    px = py = pyaw = 0.0;
+    dir = P.dir0;
+    return;
+  }
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < 5; ++k)
+    if (k < P.nseg && P.seg[k].first <= j) i = k;
+  const Seg& s = P.seg[i];
+  int m = j - s.first;
+  double pd = (m < s.n) ? s.pd0 + (double)m * s.d : s.l;
+  interp(s, pd, maxc, px, py, pyaw, dir);
+}
+
+// :656-661 -- drop trailing points whose local x is exactly 0.0
+__device__ inline void trim_path(PathPlan& P, double maxc) {
+  while (P.npts > 0) {
+    double px, py, pyaw;
+    int dir;
+    local_point(P, P.npts - 1, maxc, px, py, pyaw, dir);
+    if (px != 0.0) break;
+    P.npts--;
+  }
+}
+
+// global transform, :111-122
+__device__ inline void to_global(double lx, double ly, double lyaw, double x0, double y0, double yaw0,
+                                 double c0, double s0, double& X, double& Y, double& YAW) {
+  X = lx * c0 + ly * (-s0) + x0;   // ix cos(-yaw0) + iy sin(-yaw0) + x0
+  Y = lx * s0 + ly * c0 + y0;      // -ix sin(-yaw0) + iy cos(-yaw0) + y0
+  YAW = pp_pi_2_pi(lyaw + yaw0);
+}
+
+// hybrid_astar.rs:450-489 on the de-normalised lengths
+__host__ __device__ inline double rs_cost(const double* len, uint32_t word, int n, const PpCostParams& cp) {
+  double cost = 0.0;
+  for (int i = 0; i < n; ++i) {
+    if (len[i] >= 0.0)
+      cost += 1.0;
+    else
+      cost += fabs(len[i]) * cp.backward_cost;
+  }
+  for (int i = 0; i + 1 < n; ++i)
+    if (len[i] * len[i + 1] < 0.0) cost += cp.gear_cost;
+  for (int i = 0; i < n; ++i)
+    if (((word >> (4 * i)) & 15u) != 2u) cost += cp.steer_angle_cost * fabs(cp.max_steer);
+  double ul[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    uint32_t c = (word >> (4 * i)) & 15u;
+    if (c == 3u) ul[i] = -cp.max_steer;
+    else if (c == 1u) ul[i] = cp.max_steer;
+  }
+  for (int i = 0; i + 1 < n; ++i) cost += cp.steer_change_cost * fabs(ul[i + 1] - ul[i]);
+  return cost;
+}
+
+// ------------------------------------------------------------------ K4: analytic shot, one wave per pair
+
+__global__ void __launch_bounds__(64)
+k_rs_shot(uint32_t n, const double* __restrict__ sx, const double* __restrict__ sy,
+          const double* __restrict__ syaw, double maxc, double step_size, uint32_t check_step,
+          PpCostParams cp, const PpRsCand* __restrict__ cands, const PpRsPair* __restrict__ pairs,
+          PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice, PpShotOut* __restrict__ out) {
+  __shared__ PathPlan plans[PP_RS_MAX_PATHS];
+  __shared__ double costs[PP_RS_MAX_PATHS];
+  __shared__ uint32_t hit[PP_RS_MAX_PATHS];
+  __shared__ uint8_t gen_of[PP_RS_MAX_PATHS];
+  __shared__ uint32_t task_end[PP_RS_MAX_PATHS + 1];
+  const uint32_t pair = blockIdx.x;
+  if (pair >= n) return;
+  const int lane = threadIdx.x;
+  const PpRsPair pr = pairs[pair];
+  const PpRsCand* pc = cands + (size_t)pair * PP_RS_MAX_PATHS;
+  const int np = pr.n_paths;
+  if (lane == 0) {
+    uint64_t m = pr.accepted;
+    int k = 0;
+    while (m) {
+      gen_of[k++] = (uint8_t)__builtin_ctzll(m);
+      m &= m - 1;
+    }
+  }
+  __syncthreads();
+  const double step = step_size * maxc;
+  if (lane < np) {
+    const PpRsCand c = pc[gen_of[lane]];
+    plan_path(c, maxc, step, plans[lane]);
+    trim_path(plans[lane], maxc);
+    double len[5];
+    for (int i = 0; i < 5; ++i) len[i] = c.len[i] / maxc;
+    costs[lane] = rs_cost(len, c.word, c.nseg, cp);
+    hit[lane] = 0;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    uint32_t acc = 0;
+    for (int p = 0; p < np; ++p) {
+      task_end[p] = acc;
+      acc += (uint32_t)((plans[p].npts + (int)check_step - 1) / (int)check_step);
+    }
+    task_end[np] = acc;
+  }
+  __syncthreads();
+  const uint32_t ntask = np ? task_end[np] : 0u;
+  const double x0 = sx[pair], y0 = sy[pair], yaw0 = syaw[pair];
+  double s0, c0;
+  sincos(yaw0, &s0, &c0);
+  for (uint32_t t = lane; t < ntask; t += 64) {
+    int p = 0;
+    for (int k = 1; k < np; ++k)
+      if (task_end[k] <= t) p = k;
+    int j = (int)(t - task_end[p]) * (int)check_step;
+    double lx, ly, lyaw, X, Y, YAW;
+    int dir;
+    local_point(plans[p], j, maxc, lx, ly, lyaw, dir);
+    to_global(lx, ly, lyaw, x0, y0, yaw0, c0, s0, X, Y, YAW);
+    double s, c;
+    sincos(YAW, &s, &c);
+    unsigned r = use_lattice ? pp_pose_vs_lattice(X, Y, c, s, f, lat) : pp_pose_vs_buckets(X, Y, c, s, f, bk);
+    if (r) atomicOr(&hit[p], r);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    PpShotOut o{};
+    o.n_paths = np;
+    o.flags = pr.flags;
+    o.path_idx = -1;
+    // pop order of BinaryHeap<(Reverse(cost), i)>: cost ascending, ties -> larger i
+    uint64_t done = 0;
+    for (int it = 0; it < np; ++it) {
+      int b = -1;
+      for (int p = 0; p < np; ++p) {
+        if ((done >> p) & 1ull) continue;
+        if (b < 0 || costs[p] < costs[b] || (costs[p] == costs[b] && p > b)) b = p;
+      }
+      done |= 1ull << b;
+      if (costs[b] != costs[b]) o.flags |= 8u;  // NaN cost: NotNan::new(..).unwrap() panics
+      if (plans[b].amb) o.flags |= 2u;
+      if (hit[b] & PP_F_NONFINITE) o.flags |= 16u;
+      if (hit[b] & PP_F_AMBIG) o.flags |= 2u;
+      if (!(hit[b] & PP_F_HIT)) {
+        o.path_idx = b;
+        o.gen = gen_of[b];
+        o.cost = costs[b];
+        o.flags |= 1u;
+        break;
+      }
+    }
+    out[pair] = o;
+  }
+}
+
+// ------------------------------------------------------------------ full trajectories of one pair
+
+__global__ void __launch_bounds__(64)
+k_rs_traj(double x0, double y0, double yaw0, double maxc, double step_size,
+          const PpRsCand* __restrict__ cands, const PpRsPair* __restrict__ pairs, int only_rank,
+          uint64_t* __restrict__ traj_off, double* __restrict__ tx, double* __restrict__ ty,
+          double* __restrict__ tyaw, int64_t* __restrict__ tdir, uint64_t cap,
+          uint32_t* __restrict__ status) {
+  __shared__ PathPlan plans[PP_RS_MAX_PATHS];
+  __shared__ uint8_t gen_of[PP_RS_MAX_PATHS];
+  __shared__ uint64_t off[PP_RS_MAX_PATHS + 1];
+  const int lane = threadIdx.x;
+  const PpRsPair pr = pairs[0];
+  const int np = pr.n_paths;
+  if (lane == 0) {
+    uint64_t m = pr.accepted;
+    int k = 0;
+    while (m) {
+      gen_of[k++] = (uint8_t)__builtin_ctzll(m);
+      m &= m - 1;
+    }
+  }
+  __syncthreads();
+  const double step = step_size * maxc;
+  if (lane < np) {
+    plan_path(cands[gen_of[lane]], maxc, step, plans[lane]);
+    trim_path(plans[lane], maxc);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    uint64_t acc = 0;
+    uint32_t amb = 0, empty = 0;
+    for (int p = 0; p < np; ++p) {
+      off[p] = acc;
+      if (only_rank < 0 || only_rank == p) acc += (uint64_t)plans[p].npts;
+      amb |= plans[p].amb;
+      if (plans[p].npts == 0) empty = 1;  // px.last().unwrap() on an emptied Vec panics
+    }
+    off[np] = acc;
+    for (int p = 0; p <= np; ++p) traj_off[p] = off[p];
+    status[0] = (acc > cap) ? 1u : 0u;
+    status[1] = amb;
+    status[2] = empty;
+  }
+  __syncthreads();
+  if (off[np] > cap) return;
+  double s0, c0;
+  sincos(yaw0, &s0, &c0);
+  for (int p = 0; p < np; ++p) {
+    if (only_rank >= 0 && only_rank != p) continue;
+    for (int j = lane; j < plans[p].npts; j += 64) {
+      double lx, ly, lyaw, X, Y, YAW;
+      int dir;
+      local_point(plans[p], j, maxc, lx, ly, lyaw, dir);
+      to_global(lx, ly, lyaw, x0, y0, yaw0, c0, s0, X, Y, YAW);
+      uint64_t o = off[p] + (uint64_t)j;
+      tx[o] = X;
+      ty[o] = Y;
+      tyaw[o] = YAW;
+      tdir[o] = dir;
+    }
+  }
+}
+
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+PpCostParams cost_params(const pp_config* conf) {
+  PpCostParams c;
+  c.backward_cost = conf->backward_cost;
+  c.gear_cost = conf->gear_cost;
+  c.steer_angle_cost = conf->steer_angle_cost;
+  c.steer_change_cost = conf->steer_change_cost;
+  c.max_steer = conf->max_steer;
+  return c;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- device-side API
+
+void pp_rs_words_launch(pp_ctx* ctx, uint64_t n, const double* d_q /* 6 arrays of n */, double maxc,
+                        PpRsCand* d_cands, PpRsPair* d_pairs) {
+  unsigned grid = pp_stream_grid(ctx, n, 128);
+  hipLaunchKernelGGL(k_rs_words, dim3(grid), dim3(128), 0, ctx->stream, n, d_q, d_q + n, d_q + 2 * n,
+                     d_q + 3 * n, d_q + 4 * n, d_q + 5 * n, maxc, d_cands, d_pairs);
+}
+
+void pp_rs_shot_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, uint32_t n,
+                       const double* d_q, double maxc, const PpRsCand* d_cands,
+                       const PpRsPair* d_pairs, PpShotOut* d_out) {
+  if (n == 0) return;
+  PpFootprint f = pp_make_footprint(conf);
+  uint32_t cs = (uint32_t)std::min<uint64_t>(conf->collision_check_step, 0x7fffffffu);
+  hipLaunchKernelGGL(k_rs_shot, dim3(n), dim3(64), 0, ctx->stream, n, d_q, d_q + n, d_q + 2 * (size_t)n,
+                     maxc, conf->move_step, cs, cost_params(conf), d_cands, d_pairs, f, map->lat,
+                     map->bk, map->lattice ? 1 : 0, d_out);
+}
+
+extern "C" int32_t pp_rs_batch_dev(pp_ctx* ctx, uint64_t n, const double* d_sx, const double* d_sy,
+                                   const double* d_syaw, const double* d_gx, const double* d_gy,
+                                   const double* d_gyaw, double maxc, int32_t* d_n_paths,
+                                   int32_t* d_best_idx, pp_rs_word* d_best, uint8_t* d_flags) {
+  if (!ctx) return PP_ERR_INVALID;
+  if (n == 0) return PP_OK;
+  if (!d_sx || !d_sy || !d_syaw || !d_gx || !d_gy || !d_gyaw || !d_n_paths || !d_best_idx || !d_best || !d_flags)
+    return PP_ERR_INVALID;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned grid = pp_stream_grid(ctx, n, 128);
+  hipLaunchKernelGGL(k_rs_batch, dim3(grid), dim3(128), 0, ctx->stream, n, d_sx, d_sy, d_syaw, d_gx,
+                     d_gy, d_gyaw, maxc, d_n_paths, d_best_idx, d_best, d_flags);
+  PP_HIP(ctx, hipGetLastError());
+  return PP_OK;
+}
+
+extern "C" int32_t pp_rs_batch(pp_ctx* ctx, uint64_t n, const double* sx, const double* sy,
+                               const double* syaw, const double* gx, const double* gy,
+                               const double* gyaw, double maxc, int32_t* n_paths, int32_t* best_idx,
+                               pp_rs_word* best, uint8_t* flags) {
+  if (!ctx) return PP_ERR_INVALID;
+  if (n == 0) return PP_OK;
+  if (!sx || !sy || !syaw || !gx || !gy || !gyaw || !n_paths || !best_idx || !best || !flags) return PP_ERR_INVALID;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  size_t a8 = al256(n * 8), a4 = al256(n * 4), aw = al256(n * sizeof(pp_rs_word)), a1 = al256(n);
+  int32_t st = pp_scratch_reserve(ctx, 6 * a8 + 2 * a4 + aw + a1);
+  if (st != PP_OK) return st;
+  char* b = (char*)ctx->scratch;
+  double* dq[6];
+  const double* hq[6] = {sx, sy, syaw, gx, gy, gyaw};
+  hipStream_t s = ctx->stream;
+  for (int k = 0; k < 6; ++k) {
+    dq[k] = (double*)b;
+    b += a8;
+    PP_HIP(ctx, hipMemcpyAsync(dq[k], hq[k], n * 8, hipMemcpyHostToDevice, s));
+  }
+  int32_t* d_np = (int32_t*)b; b += a4;
+  int32_t* d_bi = (int32_t*)b; b += a4;
+  pp_rs_word* d_w = (pp_rs_word*)b; b += aw;
+  uint8_t* d_f = (uint8_t*)b;
+  st = pp_rs_batch_dev(ctx, n, dq[0], dq[1], dq[2], dq[3], dq[4], dq[5], maxc, d_np, d_bi, d_w, d_f);
+  if (st != PP_OK) return st;
+  PP_HIP(ctx, hipMemcpyAsync(n_paths, d_np, n * 4, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(best_idx, d_bi, n * 4, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(best, d_w, n * sizeof(pp_rs_word), hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(flags, d_f, n, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipStreamSynchronize(s));
+  return PP_OK;
+}
+
+// Words (+ optionally trajectories) of one pair.  only_rank < 0: every path.
+int32_t pp_rs_single(pp_ctx* ctx, const double q[6], double maxc, double step_size, int only_rank,
+                     int32_t* n_paths, pp_rs_word* words, uint64_t* traj_off, double* traj_x,
+                     double* traj_y, double* traj_yaw, int64_t* traj_dir, uint64_t traj_cap,
+                     uint32_t* flags_out) {
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  const bool want_traj = traj_x != nullptr;
+  size_t o_q = 0, o_c = o_q + al256(48), o_p = o_c + al256(sizeof(PpRsCand) * PP_RS_MAX_PATHS);
+  size_t o_off = o_p + al256(sizeof(PpRsPair)), o_st = o_off + al256(8 * (PP_RS_MAX_PATHS + 1));
+  size_t o_t = o_st + 256;
+  size_t tb = want_traj ? al256(traj_cap * 8) : 0;
+  int32_t st = pp_scratch_reserve(ctx, o_t + 4 * tb);
+  if (st != PP_OK) return st;
+  char* b = (char*)ctx->scratch;
+  double* d_q = (double*)(b + o_q);
+  PpRsCand* d_c = (PpRsCand*)(b + o_c);
+  PpRsPair* d_p = (PpRsPair*)(b + o_p);
+  uint64_t* d_off = (uint64_t*)(b + o_off);
+  uint32_t* d_st = (uint32_t*)(b + o_st);
+  hipStream_t s = ctx->stream;
+  PP_HIP(ctx, hipMemcpyAsync(d_q, q, 48, hipMemcpyHostToDevice, s));
+  pp_rs_words_launch(ctx, 1, d_q, maxc, d_c, d_p);
+  PP_HIP(ctx, hipGetLastError());
+  double *d_tx = nullptr, *d_ty = nullptr, *d_tyaw = nullptr;
+  int64_t* d_td = nullptr;
+  if (want_traj) {
+    d_tx = (double*)(b + o_t);
+    d_ty = (double*)(b + o_t + tb);
+    d_tyaw = (double*)(b + o_t + 2 * tb);
+    d_td = (int64_t*)(b + o_t + 3 * tb);
+    hipLaunchKernelGGL(k_rs_traj, dim3(1), dim3(64), 0, s, q[0], q[1], q[2], maxc, step_size, d_c, d_p,
+                       only_rank, d_off, d_tx, d_ty, d_tyaw, d_td, traj_cap, d_st);
+    PP_HIP(ctx, hipGetLastError());
+  }
+  PpRsCand hc[PP_RS_MAX_PATHS];
+  PpRsPair hp;
+  uint64_t hoff[PP_RS_MAX_PATHS + 1] = {0};
+  uint32_t hst[4] = {0, 0, 0, 0};
+  PP_HIP(ctx, hipMemcpyAsync(hc, d_c, sizeof(hc), hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(&hp, d_p, sizeof(hp), hipMemcpyDeviceToHost, s));
+  if (want_traj) {
+    PP_HIP(ctx, hipMemcpyAsync(hoff, d_off, sizeof(hoff), hipMemcpyDeviceToHost, s));
+    PP_HIP(ctx, hipMemcpyAsync(hst, d_st, 16, hipMemcpyDeviceToHost, s));
+  }
+  PP_HIP(ctx, hipStreamSynchronize(s));
+  if (flags_out) *flags_out = hp.flags | (hst[1] ? 2u : 0u);
+  if (hp.flags & 4u) return PP_ERR_DEGENERATE_RS;
+  *n_paths = hp.n_paths;
+  uint64_t m = hp.accepted;
+  int k = 0;
+  while (m) {
+    int g = __builtin_ctzll(m);
+    m &= m - 1;
+    const PpRsCand& c = hc[g];
+    pp_rs_word& w = words[k++];
+    std::memset(&w, 0, sizeof(w));
+    for (int i = 0; i < c.nseg; ++i) {
+      w.lengths[i] = c.len[i] / maxc;  // :124
+      w.ctypes[i] = pp_word_letter(c.word, i);
+    }
+    w.nseg = (uint8_t)c.nseg;
+    w.total_length = c.total / maxc;   // :125
+  }
+  if (want_traj) {
+    for (int p = 0; p <= hp.n_paths; ++p) traj_off[p] = hoff[p];
+    if (hst[0]) return PP_ERR_CAPACITY;
+    if (hst[2]) return PP_ERR_DEGENERATE_RS;
+    uint64_t tot = hoff[hp.n_paths];
+    if (tot) {
+      PP_HIP(ctx, hipMemcpyAsync(traj_x, d_tx, tot * 8, hipMemcpyDeviceToHost, s));
+      PP_HIP(ctx, hipMemcpyAsync(traj_y, d_ty, tot * 8, hipMemcpyDeviceToHost, s));
+      PP_HIP(ctx, hipMemcpyAsync(traj_yaw, d_tyaw, tot * 8, hipMemcpyDeviceToHost, s));
+      PP_HIP(ctx, hipMemcpyAsync(traj_dir, d_td, tot * 8, hipMemcpyDeviceToHost, s));
+      PP_HIP(ctx, hipStreamSynchronize(s));
+    }
+  }
+  return PP_OK;
+}
+
+extern "C" int32_t pp_rs_all_paths(pp_ctx* ctx, double sx, double sy, double syaw, double gx,
+                                   double gy, double gyaw, double maxc, double step_size,
+                                   int32_t* n_paths, pp_rs_word* words, uint64_t* traj_off,
+                                   double* traj_x, double* traj_y, double* traj_yaw,
+                                   int64_t* traj_dir, uint64_t traj_cap) {
+  if (!ctx || !n_paths || !words) return PP_ERR_INVALID;
+  if (traj_x && (!traj_off || !traj_y || !traj_yaw || !traj_dir)) return PP_ERR_INVALID;
+  double q[6] = {sx, sy, syaw, gx, gy, gyaw};
+  return pp_rs_single(ctx, q, maxc, step_size, -1, n_paths, words, traj_off, traj_x, traj_y, traj_yaw,
+                      traj_dir, traj_cap, nullptr);
+}
+
+extern "C" int32_t pp_rs_optimal_path(pp_ctx* ctx, double sx, double sy, double syaw, double gx,
+                                      double gy, double gyaw, double maxc, double step_size,
+                                      pp_rs_word* word, double* traj_x, double* traj_y,
+                                      double* traj_yaw, int64_t* traj_dir, uint64_t traj_cap,
+                                      uint64_t* traj_len) {
+  if (!ctx || !word) return PP_ERR_INVALID;
+  double q[6] = {sx, sy, syaw, gx, gy, gyaw};
+  int32_t np = 0;
+  pp_rs_word words[PP_RS_MAX_PATHS];
+  int32_t st = pp_rs_single(ctx, q, maxc, step_size, -1, &np, words, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, 0, nullptr);
+  if (st != PP_OK) return st;
+  if (np == 0) return PP_ERR_EMPTY_RS;  // paths[0] panics, :76
+  int mini = 0;
+  double min_l = words[0].total_length;
+  for (int i = 0; i < np; ++i)
+    if (words[i].total_length <= min_l) {
+      min_l = words[i].total_length;
+      mini = i;
+    }
+  *word = words[mini];
+  if (traj_x) {
+    uint64_t off[PP_RS_MAX_PATHS + 1];
+    st = pp_rs_single(ctx, q, maxc, step_size, mini, &np, words, off, traj_x, traj_y, traj_yaw, traj_dir,
+                      traj_cap, nullptr);
+    if (traj_len) *traj_len = off[np];
+    if (st != PP_OK) return st;
+  }
+  return PP_OK;
+}
+
+// calc_rs_path_cost, hybrid_astar.rs:450-489
+extern "C" double pp_rs_path_cost(const pp_rs_word* w, const pp_config* conf) {
+  if (!w || !conf) return 0.0;
+  uint32_t word = 0;
+  for (int i = 0; i < w->nseg && i < 5; ++i)
+    word |= (uint32_t)(w->ctypes[i] == 'L' ? 1 : (w->ctypes[i] == 'S' ? 2 : 3)) << (4 * i);
+  return rs_cost(w->lengths, word, w->nseg, cost_params(conf));
+}
+
+extern "C" int32_t pp_analytic_batch(pp_ctx* ctx, const pp_map* map, const pp_config* conf,
+                                     uint64_t n, const double* sx, const double* sy,
+                                     const double* syaw, const double* gx, const double* gy,
+                                     const double* gyaw, uint8_t* found, int32_t* path_idx,
+                                     int32_t* n_paths, pp_rs_word* word, double* rs_cost_out) {
+  if (!ctx || !map || !conf) return PP_ERR_INVALID;
+  if (map->ox.empty()) return PP_ERR_EMPTY_MAP;
+  if (!map->finite) return PP_ERR_NONFINITE;
+  if (n == 0) return PP_OK;
+  if (n > 0x7fffffffu) return PP_ERR_UNSUPPORTED;
+  if (!sx || !sy || !syaw || !gx || !gy || !gyaw || !found || !path_idx || !n_paths || !word || !rs_cost_out)
+    return PP_ERR_INVALID;
+  int32_t st = pp_check_config(conf);
+  if (st != PP_OK) return st;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  size_t ac = al256(n * PP_RS_MAX_PATHS * sizeof(PpRsCand)), ap = al256(n * sizeof(PpRsPair));
+  size_t ao = al256(n * sizeof(PpShotOut));
+  const double* hq[6] = {sx, sy, syaw, gx, gy, gyaw};
+  hipStream_t s = ctx->stream;
+  // the six arrays go back to back, as the launch helpers expect
+  std::vector<double> packed(6 * n);
+  for (int k = 0; k < 6; ++k) std::memcpy(packed.data() + k * n, hq[k], n * 8);
+  st = pp_scratch_reserve(ctx, al256(6 * n * 8) + ac + ap + ao);
+  if (st != PP_OK) return st;
+  char* b = (char*)ctx->scratch;
+  double* d_q = (double*)b;
+  PpRsCand* d_c = (PpRsCand*)(b + al256(6 * n * 8));
+  PpRsPair* d_p = (PpRsPair*)((char*)d_c + ac);
+  PpShotOut* d_o = (PpShotOut*)((char*)d_p + ap);
+  PP_HIP(ctx, hipMemcpyAsync(d_q, packed.data(), 6 * n * 8, hipMemcpyHostToDevice, s));
+  double maxc = std::tan(conf->max_steer) / conf->car.wheel_base;  // hybrid_astar.rs:388
+  pp_rs_words_launch(ctx, n, d_q, maxc, d_c, d_p);
+  pp_rs_shot_launch(ctx, map, conf, (uint32_t)n, d_q, maxc, d_c, d_p, d_o);
+  PP_HIP(ctx, hipGetLastError());
+  std::vector<PpShotOut> ho(n);
+  std::vector<PpRsCand> hc(n * PP_RS_MAX_PATHS);
+  PP_HIP(ctx, hipMemcpyAsync(ho.data(), d_o, n * sizeof(PpShotOut), hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(hc.data(), d_c, n * PP_RS_MAX_PATHS * sizeof(PpRsCand), hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipStreamSynchronize(s));
+  int32_t ret = PP_OK;
+  for (uint64_t i = 0; i < n; ++i) {
+    const PpShotOut& o = ho[i];
+    found[i] = (uint8_t)((o.flags & 1u) | (o.flags & 2u) | (o.flags & 4u));
+    path_idx[i] = o.path_idx;
+    n_paths[i] = o.n_paths;
+    std::memset(&word[i], 0, sizeof(pp_rs_word));
+    rs_cost_out[i] = 0.0;
+    if (o.flags & 8u) ret = PP_ERR_NAN_COST;
+    if (o.flags & 16u) ret = PP_ERR_NONFINITE;
+    if (o.path_idx >= 0) {
+      const PpRsCand& c = hc[i * PP_RS_MAX_PATHS + o.gen];
+      for (int k = 0; k < c.nseg; ++k) {
+        word[i].lengths[k] = c.len[k] / maxc;
+        word[i].ctypes[k] = pp_word_letter(c.word, k);
+      }
+      word[i].nseg = (uint8_t)c.nseg;
+      word[i].total_length = c.total / maxc;
+      rs_cost_out[i] = o.cost;
+    }
+  }
+  return ret;
+}

@@ -1,0 +1,385 @@
+// pp_rs_device.h -- Reeds-Shepp word generation on the device (reeds_shepp.rs:130-580, :707-757).
+//
+// One lane evaluates every candidate word of one (start, goal) pair.  The reference's 46 call
+// sites are 12 groups (base formula, optional "backwards" point, length layout) times up to four
+// mirror images of (x, y, phi):
+//   k=0 ( x,  y,  phi)  lengths +, word as written
+//   k=1 (-x,  y, -phi)  lengths -, word as written          (time flip)
+//   k=2 ( x, -y, -phi)  lengths +, L<->R swapped            (reflection)
+//   k=3 (-x, -y,  phi)  lengths -, L<->R swapped
+// sin(-phi) = -sin(phi) and cos(-phi) = cos(phi) hold exactly, so sin/cos of phi are computed
+// once per pair and handed to the formulas with the sign applied.
+//
+// set_path's duplicate filter (:136-149) only compares words with identical letters, and equal
+// letters occur in at most four candidates, always generated in a fixed relative order; the
+// candidates are therefore evaluated word by word with a four-entry register list per word, and
+// the reference's generation index (needed for tie-breaks and path numbering) is carried along.
+#ifndef PP_RS_DEVICE_H_
+#define PP_RS_DEVICE_H_
+
+#include "pp_internal.h"
+
+#define PP_RS_GUARD 1.0e-9
+#define PP_RS_PI 3.14159265358979323846
+
+struct PpTuv {
+  bool ok;
+  double t, u, v;
+};
+
+// Accumulates "a comparison was decided inside the guard band".
+struct PpAmb {
+  bool amb;
+  __device__ __forceinline__ bool ge(double a, double b) { amb |= fabs(a - b) < PP_RS_GUARD; return a >= b; }
+  __device__ __forceinline__ bool le(double a, double b) { amb |= fabs(a - b) < PP_RS_GUARD; return a <= b; }
+  __device__ __forceinline__ bool gt(double a, double b) { amb |= fabs(a - b) < PP_RS_GUARD; return a > b; }
+  __device__ __forceinline__ bool lt(double a, double b) { amb |= fabs(a - b) < PP_RS_GUARD; return a < b; }
+};
+
+// reeds_shepp.rs:747-757
+__device__ __forceinline__ double pp_mod2pi(double theta, PpAmb& A) {
+  double phi = fmod(theta, 2.0 * PP_RS_PI);
+  if (A.lt(phi, -PP_RS_PI)) phi += 2.0 * PP_RS_PI;
+  if (A.gt(phi, PP_RS_PI)) phi -= 2.0 * PP_RS_PI;
+  return phi;
+}
+// reeds_shepp.rs:727-738
+__device__ __forceinline__ double pp_pi_2_pi(double theta) {
+  if (!(fabs(theta) < 1.0e9)) return theta;  // the reference would loop for ages; leave as is
+  while (theta > PP_RS_PI) theta -= 2.0 * PP_RS_PI;
+  while (theta < -PP_RS_PI) theta += 2.0 * PP_RS_PI;
+  return theta;
+}
+
+// Base formulas; sp / cp are sin(phi) / cos(phi) of the phi passed in.
+// :213-229
+__device__ __forceinline__ PpTuv pp_f_sls(double x, double y, double phi, PpAmb& A) {
+  PpTuv r{false, 0., 0., 0.};
+  double p = pp_mod2pi(phi, A);
+  bool pos = A.gt(y, 0.), neg = A.lt(y, 0.);
+  bool rng = A.lt(0., p) & A.lt(p, PP_RS_PI * 0.99);
+  if ((pos | neg) & rng) {
+    double tp = tan(p), th = tan(p / 2.);
+    double xd = -y / tp + x;
+    double t = xd - th;
+    double rt = sqrt((x - xd) * (x - xd) + y * y);
+    double v = pos ? (rt - th) : (-rt - th);
+    r = PpTuv{true, t, p, v};
+  }
+  return r;
+}
+// :161-170
+__device__ __forceinline__ PpTuv pp_f_lsl(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+  PpTuv r{false, 0., 0., 0.};
+  double ax = x - sp, ay = y - 1.0 + cp;
+  double u = hypot(ax, ay), t = atan2(ay, ax);
+  if (A.ge(t, 0.0)) {
+    double v = pp_mod2pi(phi - t, A);
+    if (A.ge(v, 0.0)) r = PpTuv{true, t, u, v};
+  }
+  return r;
+}
+// :172-186
+__device__ __forceinline__ PpTuv pp_f_lsr(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+  PpTuv r{false, 0., 0., 0.};
+  double ax = x + sp, ay = y - 1.0 - cp;
+  double u1 = hypot(ax, ay), t1 = atan2(ay, ax);
+  u1 = u1 * u1;
+  if (A.ge(u1, 4.)) {
+    double u = sqrt(u1 - 4.);
+    double theta = atan2(2.0, u);
+    double t = pp_mod2pi(t1 + theta, A);
+    double v = pp_mod2pi(t - phi, A);
+    if (A.ge(t, 0.) & A.ge(v, 0.0)) r = PpTuv{true, t, u, v};
+  }
+  return r;
+}
+// :188-200
+__device__ __forceinline__ PpTuv pp_f_lrl(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+  PpTuv r{false, 0., 0., 0.};
+  double ax = x - sp, ay = y - 1.0 + cp;
+  double u1 = hypot(ax, ay), t1 = atan2(ay, ax);
+  if (A.le(u1, 4.)) {
+    double u = -2. * asin(0.25 * u1);
+    double t = pp_mod2pi(t1 + 0.5 * u + PP_RS_PI, A);
+    double v = pp_mod2pi(phi - t + u, A);
+    if (A.ge(t, 0.) & A.le(u, 0.0)) r = PpTuv{true, t, u, v};
+  }
+  return r;
+}
+// :318-332
+__device__ __forceinline__ void pp_tau_omega(double u, double v, double xi, double eta, double phi,
+                                             double& tau, double& omega, PpAmb& A) {
+  double delta = pp_mod2pi(u - v, A);
+  double su, cu, sd, cd;
+  sincos(u, &su, &cu);
+  sincos(delta, &sd, &cd);
+  double a = su - sd;
+  double b = cu - cd - 1.0;
+  double t1 = atan2(eta * a - xi * b, xi * a + eta * b);
+  double t2 = 2.0 * (cd - cos(v) - cu) + 3.0;
+  tau = A.lt(t2, 0.) ? pp_mod2pi(t1 + PP_RS_PI, A) : pp_mod2pi(t1, A);
+  omega = pp_mod2pi(tau - u + v - phi, A);
+}
+// :334-347
+__device__ __forceinline__ PpTuv pp_f_lrlrn(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+  PpTuv r{false, 0., 0., 0.};
+  double xi = x + sp, eta = y - 1.0 - cp;
+  double rho = 0.25 * (2.0 + sqrt(xi * xi + eta * eta));
+  if (A.le(rho, 1.0)) {
+    double u = acos(rho), t, v;
+    pp_tau_omega(u, -u, xi, eta, phi, t, v, A);
+    if (A.ge(t, 0.) & A.le(v, 0.)) r = PpTuv{true, t, u, v};
+  }
+  return r;
+}
+// :349-364
+__device__ __forceinline__ PpTuv pp_f_lrlrp(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+  PpTuv r{false, 0., 0., 0.};
+  double xi = x + sp, eta = y - 1.0 - cp;
+  double rho = (20. - xi * xi - eta * eta) / 16.0;
+  if (A.le(0.0, rho) & A.le(rho, 1.0)) {
+    double u = -acos(rho);
+    if (A.ge(u, -0.5 * PP_RS_PI)) {
+      double t, v;
+      pp_tau_omega(u, u, xi, eta, phi, t, v, A);
+      if (A.ge(t, 0.) & A.ge(v, 0.)) r = PpTuv{true, t, u, v};
+    }
+  }
+  return r;
+}
+// :408-422
+__device__ __forceinline__ PpTuv pp_f_lrsr(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+  PpTuv r{false, 0., 0., 0.};
+  double xi = x + sp, eta = y - 1.0 - cp;
+  double rho = hypot(-eta, xi), theta = atan2(xi, -eta);
+  if (A.ge(rho, 2.0)) {
+    double t = theta;
+    double u = 2.0 - rho;
+    double v = pp_mod2pi(t + 0.5 * PP_RS_PI - phi, A);
+    if (A.ge(t, 0.0) & A.le(u, 0.0) & A.le(v, 0.0)) r = PpTuv{true, t, u, v};
+  }
+  return r;
+}
+// :423-438
+__device__ __forceinline__ PpTuv pp_f_lrsl(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+  PpTuv r{false, 0., 0., 0.};
+  double xi = x - sp, eta = y - 1.0 + cp;
+  double rho = hypot(xi, eta), theta = atan2(eta, xi);
+  if (A.ge(rho, 2.0)) {
+    double rr = sqrt(rho * rho - 4.0);
+    double u = 2.0 - rr;
+    double t = pp_mod2pi(theta + atan2(rr, -2.0), A);
+    double v = pp_mod2pi(phi - 0.5 * PP_RS_PI - t, A);
+    if (A.ge(t, 0.0) & A.le(u, 0.0) & A.le(v, 0.0)) r = PpTuv{true, t, u, v};
+  }
+  return r;
+}
+// :526-542
+__device__ __forceinline__ PpTuv pp_f_lrslr(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+  PpTuv r{false, 0., 0., 0.};
+  double xi = x + sp, eta = y - 1.0 - cp;
+  double rho = hypot(xi, eta);
+  if (A.ge(rho, 2.0)) {
+    double u = 4.0 - sqrt(rho * rho - 4.0);
+    if (A.le(u, 0.)) {
+      double t = pp_mod2pi(atan2((4.0 - u) * xi - 2.0 * eta, -2.0 * xi + (u - 4.0) * eta), A);
+      double v = pp_mod2pi(t - phi, A);
+      if (A.ge(t, 0.0) & A.ge(v, 0.0)) r = PpTuv{true, t, u, v};
+    }
+  }
+  return r;
+}
+
+enum { PP_F_SLS_, PP_F_LSL_, PP_F_LSR_, PP_F_LRL_, PP_F_LRLRN_, PP_F_LRLRP_, PP_F_LRSL_, PP_F_LRSR_, PP_F_LRSLR_ };
+enum { PP_TUV, PP_VUT, PP_T_U_NU_V, PP_T_U_U_V, PP_T_H_U_V, PP_V_U_H_T, PP_T_H_U_H_V };
+
+// Word letters packed 4 bits each (1 = 'L', 2 = 'S', 3 = 'R'), first letter in the low nibble.
+__host__ __device__ constexpr uint32_t pp_word(const char* w) {
+  uint32_t v = 0;
+  for (int i = 0; w[i]; ++i) v |= (uint32_t)(w[i] == 'L' ? 1 : (w[i] == 'S' ? 2 : 3)) << (4 * i);
+  return v;
+}
+__host__ __device__ constexpr uint32_t pp_word_reflect(uint32_t w) {
+  uint32_t v = 0;
+  for (int i = 0; i < 5; ++i) {
+    uint32_t c = (w >> (4 * i)) & 15u;
+    v |= (c == 1 ? 3u : (c == 3 ? 1u : c)) << (4 * i);
+  }
+  return v;
+}
+__host__ __device__ inline uint8_t pp_word_letter(uint32_t w, int i) {
+  uint32_t c = (w >> (4 * i)) & 15u;
+  return c == 1 ? 'L' : (c == 2 ? 'S' : (c == 3 ? 'R' : 0));
+}
+
+// Receiver of accepted words, in the order candidates are evaluated (NOT generation order):
+//   void operator()(int gen_index, uint32_t word, int nseg, const double len[5], double total)
+// `len` and `total` are in normalised (curvature) units.
+
+// The accepted entries of one word (at most four), for set_path's duplicate test.
+template <int N>
+struct PpWordSet {
+  double len[4][N];
+  int cnt = 0;
+};
+
+struct PpRsState {
+  PpAmb A{false};
+  bool degenerate = false;  // assert!(total_length >= 0.01) would fire (:157)
+  uint64_t accepted = 0;    // bit i: candidate with generation index i became a path
+};
+
+// set_path, :130-159, for one candidate of word set `ws`.
+template <int N, class Sink>
+__device__ __forceinline__ void pp_set_path(PpRsState& S, PpWordSet<N>& ws, const double (&len)[N],
+                                            int gen, uint32_t word, Sink& sink) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (e < ws.cnt) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) s += ws.len[e][i] - len[i];
+      if (S.A.le(s, 0.01)) return;  // an equal word exists
+    }
+  }
+  double total = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) total += fabs(len[i]);
+  if (S.A.ge(total, 1000.0)) return;  // MAX_LENGTH (:6)
+  if (!S.A.ge(total, 0.01)) {
+    S.degenerate = true;
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (e == ws.cnt) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) ws.len[e][i] = len[i];
+    }
+  ws.cnt++;
+  S.accepted |= 1ull << gen;
+  double l5[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < N; ++i) l5[i] = len[i];
+  sink(gen, word, N, l5, total);
+}
+
+struct PpRsInput {
+  double x, y, phi, sp, cp, xb, yb;
+};
+
+template <int F>
+__device__ __forceinline__ PpTuv pp_eval(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+  if (F == PP_F_SLS_) return pp_f_sls(x, y, phi, A);
+  if (F == PP_F_LSL_) return pp_f_lsl(x, y, phi, sp, cp, A);
+  if (F == PP_F_LSR_) return pp_f_lsr(x, y, phi, sp, cp, A);
+  if (F == PP_F_LRL_) return pp_f_lrl(x, y, phi, sp, cp, A);
+  if (F == PP_F_LRLRN_) return pp_f_lrlrn(x, y, phi, sp, cp, A);
+  if (F == PP_F_LRLRP_) return pp_f_lrlrp(x, y, phi, sp, cp, A);
+  if (F == PP_F_LRSL_) return pp_f_lrsl(x, y, phi, sp, cp, A);
+  if (F == PP_F_LRSR_) return pp_f_lrsr(x, y, phi, sp, cp, A);
+  return pp_f_lrslr(x, y, phi, sp, cp, A);
+}
+
+// One candidate: formula F on mirror image K of the (optionally backwards) point, laid out by
+// LAY into N lengths, offered to word set `ws`.
+template <int F, int K, bool BACK, int LAY, int N, class Sink>
+__device__ __forceinline__ void pp_candidate(PpRsState& S, const PpRsInput& in, PpWordSet<N>& ws,
+                                             int gen, uint32_t word_k0, Sink& sink) {
+  const double bx = BACK ? in.xb : in.x, by = BACK ? in.yb : in.y;
+  const double ax = (K & 1) ? -bx : bx;
+  const double ay = (K & 2) ? -by : by;
+  const bool negphi = (K == 1 || K == 2);
+  const double ap = negphi ? -in.phi : in.phi;
+  const double sp = negphi ? -in.sp : in.sp;
+  PpTuv r = pp_eval<F>(ax, ay, ap, sp, in.cp, S.A);
+  if (!r.ok) return;
+  const double H = 0.5 * PP_RS_PI;
+  double len[N];
+  if constexpr (LAY == PP_TUV) { len[0] = r.t; len[1] = r.u; len[2] = r.v; }
+  if constexpr (LAY == PP_VUT) { len[0] = r.v; len[1] = r.u; len[2] = r.t; }
+  if constexpr (LAY == PP_T_U_NU_V) { len[0] = r.t; len[1] = r.u; len[2] = -r.u; len[3] = r.v; }
+  if constexpr (LAY == PP_T_U_U_V) { len[0] = r.t; len[1] = r.u; len[2] = r.u; len[3] = r.v; }
+  if constexpr (LAY == PP_T_H_U_V) { len[0] = r.t; len[1] = -H; len[2] = r.u; len[3] = r.v; }
+  if constexpr (LAY == PP_V_U_H_T) { len[0] = r.v; len[1] = r.u; len[2] = -H; len[3] = r.t; }
+  if constexpr (LAY == PP_T_H_U_H_V) { len[0] = r.t; len[1] = -H; len[2] = r.u; len[3] = -H; len[4] = r.v; }
+  if (K & 1) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) len[i] = -len[i];
+  }
+  const uint32_t word = (K & 2) ? pp_word_reflect(word_k0) : word_k0;
+  pp_set_path<N>(S, ws, len, gen, word, sink);
+}
+
+// The candidates of one group that share a word: mirror images K0 and K0+1.
+template <int F, int K0, bool BACK, int LAY, int N, class Sink>
+__device__ __forceinline__ void pp_pair(PpRsState& S, const PpRsInput& in, PpWordSet<N>& ws, int gen0,
+                                        uint32_t word_k0, Sink& sink) {
+  pp_candidate<F, K0, BACK, LAY, N>(S, in, ws, gen0 + K0, word_k0, sink);
+  pp_candidate<F, K0 + 1, BACK, LAY, N>(S, in, ws, gen0 + K0 + 1, word_k0, sink);
+}
+
+// generate_path, :707-725.
+template <class Sink>
+__device__ __forceinline__ void pp_rs_generate(double sx, double sy, double syaw, double gx, double gy,
+                                               double gyaw, double maxc, PpRsState& S, Sink& sink) {
+  const double dx = gx - sx, dy = gy - sy, dth = gyaw - syaw;
+  double s0, c0;
+  sincos(syaw, &s0, &c0);
+  PpRsInput in;
+  in.x = (c0 * dx + s0 * dy) * maxc;
+  in.y = (-s0 * dx + c0 * dy) * maxc;
+  in.phi = dth;
+  sincos(dth, &in.sp, &in.cp);
+  in.xb = in.x * in.cp + in.y * in.sp;  // :294-295, :482-483
+  in.yb = in.x * in.sp - in.y * in.cp;
+
+  {  // scs :202-211 -- generation indices 0, 1
+    PpWordSet<3> a, b;
+    pp_candidate<PP_F_SLS_, 0, false, PP_TUV, 3>(S, in, a, 0, pp_word("SLS"), sink);
+    pp_candidate<PP_F_SLS_, 2, false, PP_TUV, 3>(S, in, b, 1, pp_word("SLS"), sink);
+  }
+  {  // csc :231-270 -- 2..9
+    PpWordSet<3> a, b, c, d;
+    pp_pair<PP_F_LSL_, 0, false, PP_TUV, 3>(S, in, a, 2, pp_word("LSL"), sink);
+    pp_pair<PP_F_LSL_, 2, false, PP_TUV, 3>(S, in, b, 2, pp_word("LSL"), sink);
+    pp_pair<PP_F_LSR_, 0, false, PP_TUV, 3>(S, in, c, 6, pp_word("LSR"), sink);
+    pp_pair<PP_F_LSR_, 2, false, PP_TUV, 3>(S, in, d, 6, pp_word("LSR"), sink);
+  }
+  {  // ccc :272-316 -- 10..17; LRL / RLR each collect four candidates
+    PpWordSet<3> a, b;
+    pp_pair<PP_F_LRL_, 0, false, PP_TUV, 3>(S, in, a, 10, pp_word("LRL"), sink);
+    pp_pair<PP_F_LRL_, 0, true, PP_VUT, 3>(S, in, a, 14, pp_word("LRL"), sink);
+    pp_pair<PP_F_LRL_, 2, false, PP_TUV, 3>(S, in, b, 10, pp_word("LRL"), sink);
+    pp_pair<PP_F_LRL_, 2, true, PP_VUT, 3>(S, in, b, 14, pp_word("LRL"), sink);
+  }
+  {  // cccc :366-406 -- 18..25
+    PpWordSet<4> a, b;
+    pp_pair<PP_F_LRLRN_, 0, false, PP_T_U_NU_V, 4>(S, in, a, 18, pp_word("LRLR"), sink);
+    pp_pair<PP_F_LRLRP_, 0, false, PP_T_U_U_V, 4>(S, in, a, 22, pp_word("LRLR"), sink);
+    pp_pair<PP_F_LRLRN_, 2, false, PP_T_U_NU_V, 4>(S, in, b, 18, pp_word("LRLR"), sink);
+    pp_pair<PP_F_LRLRP_, 2, false, PP_T_U_U_V, 4>(S, in, b, 22, pp_word("LRLR"), sink);
+  }
+  {  // ccsc :440-524 -- 26..41
+    PpWordSet<4> a, b, c, d;
+    pp_pair<PP_F_LRSL_, 0, false, PP_T_H_U_V, 4>(S, in, a, 26, pp_word("LRSL"), sink);
+    pp_pair<PP_F_LRSL_, 2, false, PP_T_H_U_V, 4>(S, in, b, 26, pp_word("LRSL"), sink);
+    pp_pair<PP_F_LRSR_, 0, false, PP_T_H_U_V, 4>(S, in, c, 30, pp_word("LRSR"), sink);
+    pp_pair<PP_F_LRSR_, 2, false, PP_T_H_U_V, 4>(S, in, d, 30, pp_word("LRSR"), sink);
+  }
+  {
+    PpWordSet<4> a, b, c, d;
+    pp_pair<PP_F_LRSL_, 0, true, PP_V_U_H_T, 4>(S, in, a, 34, pp_word("LSRL"), sink);
+    pp_pair<PP_F_LRSL_, 2, true, PP_V_U_H_T, 4>(S, in, b, 34, pp_word("LSRL"), sink);
+    pp_pair<PP_F_LRSR_, 0, true, PP_V_U_H_T, 4>(S, in, c, 38, pp_word("RSRL"), sink);
+    pp_pair<PP_F_LRSR_, 2, true, PP_V_U_H_T, 4>(S, in, d, 38, pp_word("RSRL"), sink);
+  }
+  {  // ccscc :544-580 -- 42..45
+    PpWordSet<5> a, b;
+    pp_pair<PP_F_LRSLR_, 0, false, PP_T_H_U_H_V, 5>(S, in, a, 42, pp_word("LRSLR"), sink);
+    pp_pair<PP_F_LRSLR_, 2, false, PP_T_H_U_H_V, 5>(S, in, b, 42, pp_word("LRSLR"), sink);
+  }
+}
+
+#endif

@@ -1097,6 +1097,9 @@ inline uint64_t calc_index(const Node& n, const pp_param& P) {
 
 }  // namespace
 
+static uint64_t g_max_expansions = 0;
+void orc_set_max_expansions(uint64_t n) { g_max_expansions = n; }
+
 int32_t orc_plan(const orc_map* m, const pp_config* conf_, const double start[3],
                  const double goal[3], pp_path* out, pp_plan_stats* stats) {
   if (!m || !conf_ || !start || !goal || !out) return PP_ERR_INVALID;
@@ -1174,6 +1177,7 @@ int32_t orc_plan(const orc_map* m, const pp_config* conf_, const double start[3]
   S->rs_final_length = 0.0;
 
   while (!open_set.empty()) {
+    if (g_max_expansions && S->expansions >= g_max_expansions) return PP_ERR_LIMIT;
     HeapEnt e = pq.top();
     pq.pop();
     uint64_t ind = e.ind;

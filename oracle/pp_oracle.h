@@ -90,7 +90,9 @@ int32_t orc_analytic_batch(const orc_map *m, const pp_config *conf, uint64_t n, 
                            int32_t *path_idx, int32_t *n_paths, pp_rs_word *word,
                            double *rs_cost);
 
-/* src/hybrid_astar.rs:89-250 */
+/* src/hybrid_astar.rs:89-250.  orc_set_max_expansions: cap on closed nodes (0 = none, the
+ * reference's behaviour; it does not terminate on unreachable goals); PP_ERR_LIMIT when hit. */
+void orc_set_max_expansions(uint64_t n);
 int32_t orc_plan(const orc_map *m, const pp_config *conf, const double start[3],
                  const double goal[3], pp_path *out, pp_plan_stats *stats);
 

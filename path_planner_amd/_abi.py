@@ -22,6 +22,7 @@ PP_ERR_CAPACITY = -7
 PP_ERR_NONFINITE = -8
 PP_ERR_EMPTY_MAP = -9
 PP_ERR_UNSUPPORTED = -10
+PP_ERR_LIMIT = -11
 
 PP_RS_MAX_SEG = 5
 PP_RS_MAX_PATHS = 46
@@ -125,6 +126,7 @@ def load_library(path=None):
         "pp_strerror": (C.c_char_p, [C.c_int32]),
         "pp_last_hip_error": (C.c_int32, [vp]),
         "pp_version": (C.c_char_p, []),
+        "pp_ctx_set_max_expansions": (C.c_int32, [vp, C.c_uint64]),
         "pp_map_create": (C.c_int32, [vp, d, d, C.c_uint64, C.POINTER(vp)]),
         "pp_map_create_raster": (C.c_int32, [vp, u8, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64,
                                              C.POINTER(vp)]),

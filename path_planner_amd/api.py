@@ -44,6 +44,9 @@ class Context:
         self.h = h
         self.device = device
 
+    def set_max_expansions(self, n):
+        _chk(self.lib.pp_ctx_set_max_expansions(self.h, n), "pp_ctx_set_max_expansions")
+
     def synchronize(self):
         _chk(self.lib.pp_ctx_synchronize(self.h), "pp_ctx_synchronize")
 
@@ -276,7 +279,7 @@ def hybrid_astar_planning(ctx, omap, conf, sx, sy, syaw, gx, gy, gyaw, cap=20000
     stats.closed_cap = closed_cap
     stats.closed_order = _p(closed, C.c_uint64)
     st = ctx.lib.pp_plan(ctx.h, omap.h, C.byref(conf), _p(s), _p(g), C.byref(path), C.byref(stats))
-    _chk(st, "pp_plan", (A.PP_OK, A.PP_NO_PATH))
+    _chk(st, "pp_plan", (A.PP_OK, A.PP_NO_PATH, A.PP_ERR_LIMIT))
     n = int(path.len) if st == A.PP_OK else 0
     return {"status": st, "x": x[:n].copy(), "y": y[:n].copy(), "yaw": yaw[:n].copy(),
             "dir": dirs[:n].copy(), "cost": path.cost, "stats": stats,

@@ -44,7 +44,7 @@ static int32_t launch_collision(pp_ctx* ctx, const pp_map* map, const pp_config*
 
 static int32_t check_args(pp_ctx* ctx, const pp_map* map, const pp_config* conf) {
   if (!ctx || !map || !conf) return PP_ERR_INVALID;
-  if (map->ctx && map->ctx->device != ctx->device) return PP_ERR_INVALID;
+  if (map->device != ctx->device) return PP_ERR_INVALID;
   if (map->ox.empty()) return PP_ERR_EMPTY_MAP;
   if (!map->finite) return PP_ERR_NONFINITE;
   return PP_OK;

@@ -20,6 +20,7 @@ extern "C" const char* pp_strerror(int32_t st) {
     case PP_ERR_NONFINITE: return "non-finite coordinate (kdtree would return Err)";
     case PP_ERR_EMPTY_MAP: return "empty obstacle list";
     case PP_ERR_UNSUPPORTED: return "unsupported";
+    case PP_ERR_LIMIT: return "expansion limit reached (the reference would keep searching)";
   }
   return "unknown status";
 }
@@ -64,6 +65,12 @@ extern "C" void* pp_ctx_stream(pp_ctx* ctx) { return ctx ? (void*)ctx->stream : 
 extern "C" int32_t pp_ctx_synchronize(pp_ctx* ctx) {
   if (!ctx) return PP_ERR_INVALID;
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PP_OK;
+}
+
+extern "C" int32_t pp_ctx_set_max_expansions(pp_ctx* ctx, uint64_t max_expansions) {
+  if (!ctx) return PP_ERR_INVALID;
+  ctx->max_expansions = max_expansions;
   return PP_OK;
 }
 
@@ -265,6 +272,7 @@ extern "C" int32_t pp_map_create(pp_ctx* ctx, const double* ox, const double* oy
   PP_HIP(ctx, hipSetDevice(ctx->device));
   pp_map* m = new pp_map();
   m->ctx = ctx;
+  m->device = ctx->device;
   m->ox.assign(ox, ox + n);
   m->oy.assign(oy, oy + n);
   return finish_map(ctx, m, out);
@@ -277,6 +285,7 @@ extern "C" int32_t pp_map_create_raster(pp_ctx* ctx, const uint8_t* occ, uint64_
   PP_HIP(ctx, hipSetDevice(ctx->device));
   pp_map* m = new pp_map();
   m->ctx = ctx;
+  m->device = ctx->device;
   for (uint64_t y = 0; y < height; ++y)
     for (uint64_t x = 0; x < width; ++x)
       if (occ[y * width + x]) {
@@ -288,10 +297,8 @@ extern "C" int32_t pp_map_create_raster(pp_ctx* ctx, const uint8_t* occ, uint64_
 
 extern "C" void pp_map_destroy(pp_map* m) {
   if (!m) return;
-  if (m->ctx) {
-    (void)hipSetDevice(m->ctx->device);
-    (void)hipStreamSynchronize(m->ctx->stream);
-  }
+  // the context may already be gone; hipFree waits for work that still uses the buffers
+  (void)hipSetDevice(m->device);
   map_free_device(m);
   delete m;
 }

@@ -24,6 +24,13 @@ struct PpExpandDev {
   double* end_x;
   double* end_y;
   double* end_yaw;
+  // optional: calc_hybrid_cost (hybrid_astar.rs:491-493) of every valid node,
+  // cost + h_cost * hmap[xind - minx][yind - miny], with the heuristic grid of the parent's query
+  double* fcost = nullptr;
+  const double* const* hmaps = nullptr;  // table of heuristic grids (x-major, hxw x hyw)
+  const int32_t* hmap_id = nullptr;      // per parent: index into hmaps
+  uint64_t hxw = 0, hyw = 0;
+  double h_cost = 0.0;
 };
 
 struct PpExpandPlan {

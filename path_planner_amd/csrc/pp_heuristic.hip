@@ -428,7 +428,7 @@ static void heuristic_dims(const pp_map* map, double reso, uint64_t dims[6]) {
   dims[5] = dims[3] - dims[1];
 }
 
-static int32_t obsmap_dev(pp_ctx* ctx, const pp_map* map, double reso, double rr,
+int32_t pp_obsmap_dev(pp_ctx* ctx, const pp_map* map, double reso, double rr,
                           const uint64_t dims[6], uint8_t* d_obs) {
   uint64_t ncells = dims[4] * dims[5];
   PP_HIP(ctx, hipMemsetAsync(d_obs, 0, ncells, ctx->stream));
@@ -440,7 +440,7 @@ static int32_t obsmap_dev(pp_ctx* ctx, const pp_map* map, double reso, double rr
   return PP_OK;
 }
 
-static int32_t heuristic_checks(pp_ctx* ctx, const pp_map* map, double reso, uint64_t dims[6]) {
+int32_t pp_heuristic_checks(pp_ctx* ctx, const pp_map* map, double reso, uint64_t dims[6]) {
   if (!ctx || !map) return PP_ERR_INVALID;
   if (map->ox.empty()) return PP_ERR_EMPTY_MAP;
   if (!map->finite) return PP_ERR_NONFINITE;
@@ -456,7 +456,7 @@ static int32_t heuristic_checks(pp_ctx* ctx, const pp_map* map, double reso, uin
 extern "C" int32_t pp_obsmap(pp_ctx* ctx, const pp_map* map, double reso, double rr,
                              uint8_t* obsmap, uint64_t cap, uint64_t dims_out[6]) {
   uint64_t dims[6];
-  int32_t st = heuristic_checks(ctx, map, reso, dims);
+  int32_t st = pp_heuristic_checks(ctx, map, reso, dims);
   if (st != PP_OK) return st;
   if (dims_out) std::memcpy(dims_out, dims, sizeof(dims));
   uint64_t ncells = dims[4] * dims[5];
@@ -467,7 +467,7 @@ extern "C" int32_t pp_obsmap(pp_ctx* ctx, const pp_map* map, double reso, double
   st = pp_scratch_reserve(ctx, ncells);
   if (st != PP_OK) return st;
   uint8_t* d_obs = (uint8_t*)ctx->scratch;
-  st = obsmap_dev(ctx, map, reso, rr, dims, d_obs);
+  st = pp_obsmap_dev(ctx, map, reso, rr, dims, d_obs);
   if (st != PP_OK) return st;
   PP_HIP(ctx, hipMemcpyAsync(obsmap, d_obs, ncells, hipMemcpyDeviceToHost, ctx->stream));
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -482,7 +482,7 @@ int32_t pp_heuristic_dev(pp_ctx* ctx, const pp_map* map, double gx, double gy, d
   uint64_t gyi = pp_sat_usize(std::round(gy / reso));
   if (gxi < dims[0] || gxi - dims[0] >= dims[4] || gyi < dims[1] || gyi - dims[1] >= dims[5])
     return PP_ERR_BOUNDS;
-  int32_t st = obsmap_dev(ctx, map, reso, rr, dims, d_obs);
+  int32_t st = pp_obsmap_dev(ctx, map, reso, rr, dims, d_obs);
   if (st != PP_OK) return st;
   return pp_wavefront_dev(ctx, dims[4], dims[5], d_obs, gxi - dims[0], gyi - dims[1], d_hmap, nullptr);
 }
@@ -490,7 +490,7 @@ int32_t pp_heuristic_dev(pp_ctx* ctx, const pp_map* map, double gx, double gy, d
 extern "C" int32_t pp_heuristic(pp_ctx* ctx, const pp_map* map, double gx, double gy, double reso,
                                 double rr, double* hmap, uint64_t cap, uint64_t dims_out[6]) {
   uint64_t dims[6];
-  int32_t st = heuristic_checks(ctx, map, reso, dims);
+  int32_t st = pp_heuristic_checks(ctx, map, reso, dims);
   if (st != PP_OK) return st;
   if (dims_out) std::memcpy(dims_out, dims, sizeof(dims));
   uint64_t ncells = dims[4] * dims[5];

@@ -61,6 +61,7 @@ struct pp_ctx {
   bool own_stream = false;
   int last_hip_error = 0;
   int num_cus = 256;
+  uint64_t max_expansions = 100000;  // per query, 0 = unlimited
   // reusable device scratch (grown on demand, never shrunk)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -69,7 +70,8 @@ struct pp_ctx {
 };
 
 struct pp_map {
-  pp_ctx* ctx = nullptr;
+  pp_ctx* ctx = nullptr;  // creator (not dereferenced after creation)
+  int device = 0;
   std::vector<double> ox, oy;  // the reference's lists, kept for calc_parameters / obsmap
   bool finite = true;
   bool lattice = false;
@@ -98,6 +100,11 @@ int32_t pp_scratch_reserve(pp_ctx* ctx, size_t bytes);
 int32_t pp_pinned_reserve(pp_ctx* ctx, size_t bytes);
 PpFootprint pp_make_footprint(const pp_config* conf);
 int32_t pp_check_config(const pp_config* conf);
+
+// heuristic building blocks (pp_heuristic.hip), device-resident forms used by the planner
+int32_t pp_heuristic_checks(pp_ctx* ctx, const pp_map* map, double reso, uint64_t dims[6]);
+int32_t pp_obsmap_dev(pp_ctx* ctx, const pp_map* map, double reso, double rr, const uint64_t dims[6],
+                      uint8_t* d_obs);
 
 // Rust `as usize` / `as isize` on f64 (saturating, NaN -> 0); host and device.
 __host__ __device__ inline uint64_t pp_sat_usize(double v) {

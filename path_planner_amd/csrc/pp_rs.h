@@ -25,6 +25,8 @@ struct PpShotOut {
   int32_t gen;       // generation index of that path
   int32_t n_paths;
   uint32_t flags;    // bit0 found, bit1 guard band, bit2 degenerate, bit3 NaN cost, bit4 non-finite pose
+  uint32_t poses_handed;  // poses of the popped paths' subsampled lists (handed to is_collision)
+  uint32_t pad_;
 };
 
 struct PpCostParams {

@@ -359,6 +359,7 @@ k_rs_shot(uint32_t n, const double* __restrict__ sx, const double* __restrict__ 
         if (b < 0 || costs[p] < costs[b] || (costs[p] == costs[b] && p > b)) b = p;
       }
       done |= 1ull << b;
+      o.poses_handed += task_end[b + 1] - task_end[b];
       if (costs[b] != costs[b]) o.flags |= 8u;  // NaN cost: NotNan::new(..).unwrap() panics
       if (plans[b].amb) o.flags |= 2u;
       if (hit[b] & PP_F_NONFINITE) o.flags |= 16u;

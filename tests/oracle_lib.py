@@ -57,6 +57,7 @@ def lib():
         "orc_rs_path_cost": (C.c_double, [W, cfg]),
         "orc_analytic_batch": (C.c_int32, [vp, cfg, C.c_uint64, d, d, d, d, d, d, u8, i32, i32, W, d]),
         "orc_plan": (C.c_int32, [vp, cfg, d, d, C.POINTER(A.Path), C.POINTER(A.PlanStats)]),
+        "orc_set_max_expansions": (None, [C.c_uint64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -121,6 +122,10 @@ class OracleMap:
 
     def plan(self, conf, start, goal, cap=100000, closed_cap=100000):
         return run_plan(lambda *a: lib().orc_plan(self.h, *a), conf, start, goal, cap, closed_cap)
+
+
+def set_max_expansions(n):
+    lib().orc_set_max_expansions(n)
 
 
 def run_plan(fn, conf, start, goal, cap=100000, closed_cap=100000):

@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """Benchmark of the hybrid A* hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload collision|rs|wavefront]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload collision|rs|wavefront|queries]
 
 Default workload: BASELINE.json configs[1] -- batched footprint collision check, 16 777 216
 random SE(2) poses on a 2048x2048 occupancy grid (border + Bernoulli 0.05), demo car.  One
 "step" = one pass of the collision kernel over the whole pose batch, inputs resident in HBM.
 Multi-GPU (--gpus N under torch.distributed.run): every rank checks its own 16M-pose slice of the
 stream against a replicated grid (weak scaling, no data-path collective).
+
+Other workloads: `rs` (configs[3], pairs sharded), `wavefront` (configs[2]; with N > 1 the grid is
+cut into x-slabs, one per rank, with halo-column exchange over RCCL -- fixed total size, strong
+scaling) and `queries` (configs[4]: independent planner queries sharded over the ranks, strong).
 
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (25 B/pose:
 3 x f64 in + 1 flag byte out) / the kernel's mean launch duration measured with events on the
@@ -37,11 +41,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="collision", choices=["collision", "rs", "wavefront"])
+    ap.add_argument("--workload", default="collision", choices=["collision", "rs", "wavefront", "queries"])
     ap.add_argument("--poses", type=int, default=1 << 24)
     ap.add_argument("--grid", type=int, default=2048)
     ap.add_argument("--pairs", type=int, default=1 << 20)
     ap.add_argument("--cells", type=int, default=16384, help="wavefront grid edge")
+    ap.add_argument("--queries", type=int, default=4096)
+    ap.add_argument("--map", type=int, default=4096, help="queries workload map edge")
+    ap.add_argument("--goals", type=int, default=64, help="distinct goals the queries share")
+    ap.add_argument("--max-expansions", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
     return ap.parse_args()
@@ -90,6 +98,7 @@ def main():
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ set-up
+    scaling = "weak"
     if args.workload == "collision":
         occ = W.occupancy_grid(args.grid, 0.05)
         omap = api.ObstacleMap(ctx, raster=occ)
@@ -126,20 +135,59 @@ def main():
                                          npaths.data_ptr(), best.data_ptr(), words.data_ptr(),
                                          rflags.data_ptr())
             assert st == 0, st
-    else:
+    elif args.workload == "wavefront":
+        from path_planner_amd import tiled
         ncell = args.cells
         obs_np, gx, gy = W.wavefront_obsmap(ncell, 0.2)
-        obs = torch.from_numpy(obs_np).to(dev)
-        cost = torch.empty((ncell, ncell), dtype=torch.float64, device=dev)
-        units, bytes_per_unit = ncell * ncell, BYTES_PER_CELL
+        x0, x1 = tiled.slab_bounds(ncell, world, rank)
+        units, bytes_per_unit = ncell * ncell // world, BYTES_PER_CELL
         metric, unit = "heuristic_cells_per_sec", "cells/s"
+        scaling = "strong"
         wl = {"workload": f"holonomic heuristic wavefront, {ncell}x{ncell} grid (border + "
                           "Bernoulli 0.2), goal at centre", "cells": ncell * ncell,
-              "parallelism": f"replicas x{world}"}
+              "parallelism": f"x-slabs x{world}, halo-column exchange" if world > 1 else "1 GPU"}
         dtype, kernel = "f64", "k_wave_*"
+        if world == 1:
+            obs = torch.from_numpy(obs_np).to(dev)
+            cost = torch.empty((ncell, ncell), dtype=torch.float64, device=dev)
+
+            def step():
+                api.wavefront_dev(ctx, obs, gx, gy, cost)
+        else:
+            obs_s, cost = tiled.make_slab(obs_np, ncell, ncell, x0, x1, dev)
+            solver = tiled.DeviceSlabSolver(ctx, ncell, ncell, x0, x1, obs_s, cost, (gx, gy))
+            rounds = []
+
+            def step():
+                cost.fill_(float("inf"))
+                torch.cuda.synchronize()
+                rounds.append(tiled.tiled_wavefront(solver, rank, world))
+    else:
+        occ = W.plan_map(args.map)
+        omap = api.ObstacleMap(ctx, raster=occ)
+        ctx.set_max_expansions(args.max_expansions)
+        # candidates whose start or goal pose collides are dropped (device check), then the
+        # first --queries survivors are dealt round-robin to the ranks
+        cs, cg = W.plan_queries(3 * args.queries, args.map, args.goals)
+        inside = (cs[:, 0] > 8) & (cs[:, 0] < args.map - 9) & (cs[:, 1] > 8) & (cs[:, 1] < args.map - 9)
+        fs = api.collision_flags(ctx, omap, conf, cs[:, 0], cs[:, 1], cs[:, 2])
+        fg = api.collision_flags(ctx, omap, conf, cg[:, 0], cg[:, 1], cg[:, 2])
+        keep = np.nonzero(inside & (fs == 0) & (fg == 0))[0][: args.queries]
+        assert len(keep) == args.queries, "not enough collision-free candidates"
+        mine = keep[rank::world]
+        starts, goals = cs[mine], cg[mine]
+        units, bytes_per_unit = len(mine), 0.0
+        metric, unit = "planning_queries_per_sec", "queries/s"
+        scaling = "strong"
+        wl = {"workload": f"{args.queries} hybrid A* queries on a {args.map}x{args.map} map (border + "
+                          f"clustered wall segments, density {occ.mean():.4f}), {args.goals} shared goals, "
+                          f"start 30-200 m from goal, expansion cap {args.max_expansions}",
+              "queries": args.queries, "parallelism": f"query-sharded x{world}"}
+        dtype, kernel = "f64", "k_expand+k_rs_shot"
+        last = {}
 
         def step():
-            api.wavefront_dev(ctx, obs, gx, gy, cost)
+            last["r"] = api.plan_batch(ctx, omap, conf, starts, goals, cap=4096)
 
     # ------------------------------------------------------------------ timed region
     with torch.cuda.stream(stream):
@@ -161,18 +209,40 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total_units = units * world * args.steps
+    if world > 1:
+        tu = torch.tensor([units], dtype=torch.int64, device=dev)
+        dist.all_reduce(tu)
+        total_units = int(tu.item()) * args.steps
+    else:
+        total_units = units * args.steps
     value = total_units / elapsed
 
     out = {
         "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic", "config": wl,
+        "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic", "config": wl,
     }
     achieved = units * bytes_per_unit / (dev_ms * 1e-3) / 1e9
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(args.workload),
                        "kernel": kernel, "kernel_ms": dev_ms, "bytes_per_unit": bytes_per_unit}
+    if args.workload == "queries":
+        # host-driven search: no single kernel bounds it; report the search's own counters
+        r = last["r"]
+        stt = r["stats"]
+        nq = len(r["status"])
+        out["roofline"] = None
+        out["search"] = {
+            "found": int((r["status"] == 0).sum()), "no_path": int((r["status"] == 1).sum()),
+            "cap_reached": int((r["status"] == A.PP_ERR_LIMIT).sum()),
+            "other_errors": int(((r["status"] < 0) & (r["status"] != A.PP_ERR_LIMIT)).sum()),
+            "expansions": int(sum(stt[i].expansions for i in range(nq))),
+            "poses_checked": int(sum(stt[i].poses_checked for i in range(nq))),
+            "rs_paths": int(sum(stt[i].rs_paths for i in range(nq))),
+            "t_heuristic_ms": float(stt[0].t_heuristic_ms), "t_search_ms": float(stt[0].t_search_ms),
+            "note": "counters of rank 0's shard, last step"}
+    if args.workload == "wavefront" and world > 1:
+        out["config"]["exchange_rounds"] = rounds[-1]
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -203,6 +273,26 @@ def main():
             dt = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": ns / dt, "unit": unit, "cores": 1, "kind": "port",
                                    "sample": f"first {ns} pairs, CPU oracle generate_path + argmin"}
+        elif args.workload == "queries":
+            ns = args.cpu_sample or 16
+            ox, oy = W.raster_to_points(occ)
+            om = O.OracleMap(ox, oy)
+            O.set_max_expansions(args.max_expansions)
+            r = last["r"]
+            t0 = time.perf_counter()
+            mism = 0
+            for i in range(ns):
+                e = om.plan(conf, starts[i], goals[i])
+                ok = e["status"] == r["status"][i] and e["stats"].expansions == r["stats"][i].expansions
+                if ok and e["status"] == 0:
+                    ok = abs(e["cost"] - r["cost"][i]) <= 1e-9 * abs(e["cost"]) and len(e["x"]) == r["len"][i]
+                mism += (not ok) and r["stats"][i].ambiguous == 0
+            dt = time.perf_counter() - t0
+            O.set_max_expansions(0)
+            out["cpu_baseline"] = {"value": ns / dt, "unit": unit, "cores": 1, "kind": "port",
+                                   "sample": f"first {ns} queries of rank 0's shard, CPU oracle planner "
+                                             "(heuristic recomputed per query as the reference does)",
+                                   "mismatches_vs_gpu": int(mism)}
         else:
             ns = args.cpu_sample or min(ncell, 2048)
             sub = np.ascontiguousarray(obs_np[:ns, :ns]).copy()

@@ -286,5 +286,36 @@ def hybrid_astar_planning(ctx, omap, conf, sx, sy, syaw, gx, gy, gyaw, cap=20000
             "closed": closed[: min(int(stats.expansions), closed_cap)].copy()}
 
 
+def plan_batch(ctx, omap, conf, starts, goals, cap=4096, closed_cap=0):
+    """n independent hybrid_astar_planning calls advanced together (pp_plan_batch).  Returns
+    status[n], a list-like of paths (x, y, yaw, dir arrays of shape (n, cap) with len[n], cost[n])
+    and the per-query statistics."""
+    starts = np.ascontiguousarray(_f64(starts).reshape(-1, 3))
+    goals = np.ascontiguousarray(_f64(goals).reshape(-1, 3))
+    n = len(starts)
+    X, Y, YAW = np.zeros((n, cap)), np.zeros((n, cap)), np.zeros((n, cap))
+    D = np.zeros((n, cap), np.int64)
+    closed = np.zeros((n, max(closed_cap, 1)), np.uint64)
+    paths = (A.Path * n)()
+    stats = (A.PlanStats * n)()
+    dp, ip, up = A.c_double_p, A.c_i64_p, A.c_u64_p
+    xs, ys, ws, ds, cs = (a.ctypes.data for a in (X, Y, YAW, D, closed))
+    for i in range(n):
+        o = i * cap * 8
+        paths[i] = A.Path(C.cast(xs + o, dp), C.cast(ys + o, dp), C.cast(ws + o, dp),
+                          C.cast(ds + o, ip), cap, 0, 0.0)
+        if closed_cap:
+            stats[i].closed_cap = closed_cap
+            stats[i].closed_order = C.cast(cs + i * closed_cap * 8, up)
+    status = np.zeros(n, np.int32)
+    st = ctx.lib.pp_plan_batch(ctx.h, omap.h, C.byref(conf), n, _p(starts), _p(goals), paths, stats,
+                               _p(status, C.c_int32))
+    _chk(st, "pp_plan_batch")
+    lens = np.array([paths[i].len for i in range(n)], np.int64)
+    cost = np.array([paths[i].cost for i in range(n)])
+    return {"status": status, "x": X, "y": Y, "yaw": YAW, "dir": D, "len": lens, "cost": cost,
+            "stats": stats, "closed": closed}
+
+
 def demo_maxc(conf):
     return math.tan(conf.max_steer) / conf.car.wheel_base

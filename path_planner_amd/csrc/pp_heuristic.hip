@@ -91,144 +91,230 @@ __global__ void k_obsmap(uint64_t n, const double* __restrict__ ox, const double
   }
 }
 
-// ------------------------------------------------------------------ K6: bucketed wavefront
+// ------------------------------------------------------------------ K6: tiled relaxation
+//
+// The reference's Dijkstra (astar.rs:153-198) computes the unique fixpoint of
+//   d[goal] = 0,  d[v] = min over valid neighbours n of fl(d[n] + w(n, v)),  w in {1, hypot(1,1)}
+// (each fl(d + w) is monotone in d, so relaxing from any upper bounds in any order converges to the
+// same bits).  The grid is cut into 32x32-cell tiles; a round relaxes every active tile to its
+// own fixpoint against the current values of the surrounding ring of cells, and a tile whose edge
+// cells moved activates the neighbours that see them.  One wave owns one tile: each lane keeps a
+// 4x4 patch in registers and sweeps it forward and backward (a two-pass chamfer transform), the
+// patches trade edge values through LDS, and the wave repeats until no cell moves.
 
-struct WaveGrid {
-  double* cost;          // column-major in x: cost[lx * yw + y]
+constexpr int kTile = 32;                    // cells per tile side
+constexpr int kPps = 8;                      // 4x4 patches per tile side
+constexpr int kRing = kPps + 2;              // patch grid plus the ring outside the tile
+constexpr int kSlot = kRing * kRing;         // doubles per patch-cell slot
+constexpr int kWaveLds = 16 * kSlot;         // doubles of LDS per wave
+constexpr int kWavesPerBlock = 4;
+
+struct TileGrid {
+  double* cost;          // cost[lx * yw + y]: x-major, one x-column of yw cells contiguous
   const uint8_t* obs;    // same indexing
-  uint32_t yw;
-  uint32_t ncols;        // columns stored (including halo columns for a slab)
+  uint64_t yw;
+  uint64_t ncols;        // stored columns (a slab includes its two halo columns)
   int64_t gx_off;        // global x of stored column 0
-  int64_t xw;            // global grid width (valid cells: 0 < gx < xw, 0 < y < yw)
-  uint32_t tgt_lo, tgt_hi;  // stored columns [tgt_lo, tgt_hi) may be relaxed (owned columns)
+  int64_t xw;            // global grid width
+  uint64_t own_lo, own_hi;  // stored columns [own_lo, own_hi) are relaxed, the rest only read
+  uint32_t ntx, nty;     // tiles over the owned columns
+  int64_t goal_cell;     // index of the goal cell in cost[], -1 when it is not stored here
 };
 
-struct WaveQueues {
-  uint32_t* cell[3];
-  double* qcost[3];
-  uint32_t cap;
-  uint32_t* count;     // per absolute bucket
-  uint32_t nbuckets;
-  uint32_t* status;    // [0] max bucket pushed, [1] overflow flag, [2] changed_lo, [3] changed_hi
-  // seeds expanded when the wavefront reaches their bucket (halo cells lowered by the caller)
-  const uint32_t* seed_cell;
-  const uint32_t* seed_count;
+struct TileWork {
+  uint32_t* list[2];     // tiles to relax in even / odd rounds
+  uint32_t* flag[2];     // "already listed" per tile, per parity
+  uint32_t* count;       // [3]: list lengths of rounds r, r+1, r+2 (mod 3)
+  uint32_t* status;      // [0] tile visits, [1] sweep pairs, [2] first owned column moved, [3] last
 };
 
-__device__ inline void wave_push(const WaveQueues& q, uint32_t cell, double c) {
-  double fb = floor(c);
-  uint32_t b = fb < 4.0e9 ? (uint32_t)fb : 0xFFFFFFFFu;
-  if (b >= q.nbuckets) {
-    atomicOr(&q.status[1], 2u);
-    return;
-  }
-  uint32_t slot = atomicAdd(&q.count[b], 1u);
-  if (slot >= q.cap) {
-    atomicOr(&q.status[1], 1u);
-    return;
-  }
-  q.cell[b % 3][slot] = cell;
-  q.qcost[b % 3][slot] = c;
-  atomicMax(&q.status[0], b);
+__device__ inline double pp_min_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ inline double pp_max_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
-// Relax the 8 neighbours of one final cell.  The loads, the atomic mins and the queue-slot
-// reservations are each issued as a group so their latencies overlap; a cell in bucket k only
-// ever pushes into buckets k+1 and k+2 (1 <= w < 1.5), so two reservations per lane suffice.
-__device__ inline void wave_expand(const WaveGrid& g, const WaveQueues& q, uint32_t cell, double c,
-                                   double diag, uint32_t k) {
-  const uint32_t lx = cell / g.yw, y = cell - lx * g.yw;
-  uint32_t ncell[8];
-  double nc[8];
-  bool ok[8];
-  uint8_t ob[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    // astar.rs:297-308
-    const int dx = (j == 0 || j == 1 || j == 7) ? -1 : ((j >= 3 && j <= 5) ? 1 : 0);
-    const int dy = (j >= 1 && j <= 3) ? 1 : ((j >= 5) ? -1 : 0);
-    const int64_t nlx = (int64_t)lx + dx, ny = (int64_t)y + dy, ngx = nlx + g.gx_off;
-    // owned column, and check_node's bounds (astar.rs:200-204)
-    ok[j] = nlx >= (int64_t)g.tgt_lo && nlx < (int64_t)g.tgt_hi && ngx > 0 && ngx < g.xw && ny > 0 &&
-            ny < (int64_t)g.yw;
-    ncell[j] = ok[j] ? (uint32_t)nlx * g.yw + (uint32_t)ny : cell;
-    nc[j] = c + ((dx != 0 && dy != 0) ? diag : 1.0);
+__device__ inline void tile_activate(const TileGrid& g, const TileWork& w, int64_t tx, int64_t ty,
+                                     uint32_t round) {
+  if (tx < 0 || ty < 0 || tx >= (int64_t)g.ntx || ty >= (int64_t)g.nty) return;
+  const uint32_t t = (uint32_t)tx * g.nty + (uint32_t)ty;
+  if (atomicExch(&w.flag[round & 1][t], 1u) == 0u) {
+    const uint32_t s = atomicAdd(&w.count[round % 3], 1u);
+    w.list[round & 1][s] = t;
   }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ob[j] = g.obs[ncell[j]];
-  unsigned long long old[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    ok[j] = ok[j] && ob[j] == 0;  // astar.rs:206-208
-    const unsigned long long nb = (unsigned long long)__double_as_longlong(nc[j]);
-    old[j] = ok[j] ? atomicMin((unsigned long long*)&g.cost[ncell[j]], nb) : 0ull;
-  }
-  uint32_t n1 = 0, n2 = 0;
-  const double k2 = (double)k + 2.0;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    ok[j] = ok[j] && (unsigned long long)__double_as_longlong(nc[j]) < old[j];
-    if (ok[j]) {
-      if (nc[j] < k2) ++n1; else ++n2;
-    }
-  }
-  if (n1 + n2 == 0) return;
-  const uint32_t b1 = k + 1, b2 = k + 2;
-  if (b2 >= q.nbuckets) {
-    atomicOr(&q.status[1], 2u);
-    return;
-  }
-  uint32_t s1 = n1 ? atomicAdd(&q.count[b1], n1) : 0u;
-  uint32_t s2 = n2 ? atomicAdd(&q.count[b2], n2) : 0u;
-  if ((n1 && s1 + n1 > q.cap) || (n2 && s2 + n2 > q.cap)) {
-    atomicOr(&q.status[1], 1u);
-    return;
-  }
-  uint32_t* c1 = q.cell[b1 % 3];
-  uint32_t* c2 = q.cell[b2 % 3];
-  double* v1 = q.qcost[b1 % 3];
-  double* v2 = q.qcost[b2 % 3];
-  bool edge_lo = false, edge_hi = false;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (!ok[j]) continue;
-    if (nc[j] < k2) {
-      c1[s1] = ncell[j];
-      v1[s1++] = nc[j];
-    } else {
-      c2[s2] = ncell[j];
-      v2[s2++] = nc[j];
-    }
-    const uint32_t nlx = ncell[j] / g.yw;
-    edge_lo |= nlx == g.tgt_lo;
-    edge_hi |= nlx + 1 == g.tgt_hi;
-  }
-  atomicMax(&q.status[0], n2 ? b2 : b1);
-  if (edge_lo) q.status[2] = 1;
-  if (edge_hi) q.status[3] = 1;
 }
 
-__global__ void __launch_bounds__(256)
-k_wave_step(WaveGrid g, WaveQueues q, uint32_t k, double diag) {
-  const uint32_t nq = min(q.count[k], q.cap);
-  const uint32_t ns = q.seed_count ? *q.seed_count : 0u;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t* qc = q.cell[k % 3];
-  const double* qv = q.qcost[k % 3];
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nq + ns; i += stride) {
-    uint32_t cell;
-    double c;
-    if (i < nq) {
-      cell = qc[i];
-      c = qv[i];
-      // stale entry: the cell was lowered again after this entry was queued
-      if (__double_as_longlong(g.cost[cell]) != __double_as_longlong(c)) continue;
-    } else {
-      cell = q.seed_cell[i - nq];
-      c = g.cost[cell];
-      if (!(c >= (double)k && c < (double)k + 1.0)) continue;
+__device__ inline double tile_ring_value(const TileGrid& g, int64_t x, int64_t y) {
+  if (x < 0 || y < 0 || x >= (int64_t)g.ncols || y >= (int64_t)g.yw)
+    return __longlong_as_double(0x7FF0000000000000ll);
+  return g.cost[(uint64_t)x * g.yw + (uint64_t)y];
+}
+
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
+  __shared__ double lds_all[kWavesPerBlock * kWaveLds];
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  double* lds = lds_all + wv * kWaveLds;
+  const uint32_t n = w.count[round % 3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) w.count[(round + 2) % 3] = 0;
+  const uint32_t* list = w.list[round & 1];
+  const int px = (int)(lane >> 3), py = (int)(lane & 7u);
+  const double INF = __longlong_as_double(0x7FF0000000000000ll);
+  const int own_slot = (px + 1) * kRing + (py + 1);
+
+  for (uint32_t it = blockIdx.x * kWavesPerBlock + wv; it < n; it += gridDim.x * kWavesPerBlock) {
+    const uint32_t t = list[it];
+    if (lane == 0) w.flag[round & 1][t] = 0;
+    const uint32_t tx = t / g.nty, ty = t - tx * g.nty;
+    const int64_t x0 = (int64_t)g.own_lo + (int64_t)tx * kTile, y0 = (int64_t)ty * kTile;
+
+    // e[1..4][1..4] = the lane's patch, the rest of e = the cells around it.  floor_[][] is the
+    // value a cell may not go below: 0 for a free cell, +inf for a blocked one (check_node,
+    // astar.rs:200-211), its own value for a stored cell this rank does not own.
+    double e[6][6], floor_[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t x = x0 + 4 * px + i, y = y0 + 4 * py + j;
+        double v = INF, fl = INF;
+        if (x < (int64_t)g.ncols && y < (int64_t)g.yw) {
+          const uint64_t idx = (uint64_t)x * g.yw + (uint64_t)y;
+          v = g.cost[idx];
+          if (x >= (int64_t)g.own_hi) {
+            fl = v;
+          } else {
+            const bool blocked = g.obs[idx] != 0 || x + g.gx_off <= 0 || y <= 0;
+            fl = (blocked && (int64_t)idx != g.goal_cell) ? INF : 0.0;
+          }
+        }
+        e[i + 1][j + 1] = v;
+        floor_[i][j] = fl;
+        lds[(i * 4 + j) * kSlot + own_slot] = v;
+      }
     }
-    wave_expand(g, q, cell, c, diag, k);
+    // the ring of cells just outside the tile
+    if (lane < 34) {
+      const int o = (int)lane - 1, q = (o + 4) >> 2, j = (o + 4) & 3;
+      lds[(3 * 4 + j) * kSlot + 0 * kRing + q] = tile_ring_value(g, x0 - 1, y0 + o);
+      lds[(0 * 4 + j) * kSlot + (kRing - 1) * kRing + q] = tile_ring_value(g, x0 + kTile, y0 + o);
+    }
+    if (lane < 32) {
+      const int o = (int)lane, prow = (o >> 2) + 1, i = o & 3;
+      lds[(i * 4 + 3) * kSlot + prow * kRing + 0] = tile_ring_value(g, x0 + o, y0 - 1);
+      lds[(i * 4 + 0) * kSlot + prow * kRing + (kRing - 1)] = tile_ring_value(g, x0 + o, y0 + kTile);
+    }
+
+    uint32_t sweeps = 0;
+    for (;;) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ii = 0; ii < 6; ++ii) {
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {
+          if (ii >= 1 && ii <= 4 && jj >= 1 && jj <= 4) continue;
+          const int dx = ii == 0 ? -1 : (ii == 5 ? 1 : 0), dy = jj == 0 ? -1 : (jj == 5 ? 1 : 0);
+          const int si = ii == 0 ? 3 : (ii == 5 ? 0 : ii - 1), sj = jj == 0 ? 3 : (jj == 5 ? 0 : jj - 1);
+          e[ii][jj] = lds[(si * 4 + sj) * kSlot + own_slot + dx * kRing + dy];
+        }
+      }
+#pragma unroll
+      for (int i = 1; i <= 4; ++i) {
+#pragma unroll
+        for (int j = 1; j <= 4; ++j) {
+          double v = e[i][j];
+          v = pp_min_f64(v, e[i - 1][j - 1] + diag);
+          v = pp_min_f64(v, e[i - 1][j] + 1.0);
+          v = pp_min_f64(v, e[i - 1][j + 1] + diag);
+          v = pp_min_f64(v, e[i][j - 1] + 1.0);
+          e[i][j] = pp_max_f64(v, floor_[i - 1][j - 1]);
+        }
+      }
+#pragma unroll
+      for (int i = 4; i >= 1; --i) {
+#pragma unroll
+        for (int j = 4; j >= 1; --j) {
+          double v = e[i][j];
+          v = pp_min_f64(v, e[i + 1][j + 1] + diag);
+          v = pp_min_f64(v, e[i + 1][j] + 1.0);
+          v = pp_min_f64(v, e[i + 1][j - 1] + diag);
+          v = pp_min_f64(v, e[i][j + 1] + 1.0);
+          e[i][j] = pp_max_f64(v, floor_[i - 1][j - 1]);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      bool moved = false;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double* slot = &lds[(i * 4 + j) * kSlot + own_slot];
+          const double v = e[i + 1][j + 1];
+          moved |= __double_as_longlong(*slot) != __double_as_longlong(v);
+          *slot = v;
+        }
+      }
+      ++sweeps;
+      if (__ballot(moved) == 0ull) break;
+    }
+
+    // write back what moved; cells on the tile's edge wake the neighbours that read them
+    bool m_xlo = false, m_xhi = false, m_ylo = false, m_yhi = false;
+    bool c00 = false, c01 = false, c10 = false, c11 = false, first_col = false, last_col = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int li = 4 * px + i, lj = 4 * py + j;
+        const int64_t x = x0 + li, y = y0 + lj;
+        if (x < (int64_t)g.own_hi && y < (int64_t)g.yw) {
+          const uint64_t idx = (uint64_t)x * g.yw + (uint64_t)y;
+          const double v = e[i + 1][j + 1];
+          if (__double_as_longlong(g.cost[idx]) != __double_as_longlong(v)) {
+            g.cost[idx] = v;
+            m_xlo |= li == 0;
+            m_xhi |= li == kTile - 1;
+            m_ylo |= lj == 0;
+            m_yhi |= lj == kTile - 1;
+            c00 |= li == 0 && lj == 0;
+            c01 |= li == 0 && lj == kTile - 1;
+            c10 |= li == kTile - 1 && lj == 0;
+            c11 |= li == kTile - 1 && lj == kTile - 1;
+            first_col |= x == (int64_t)g.own_lo;
+            last_col |= x + 1 == (int64_t)g.own_hi;
+          }
+        }
+      }
+    }
+    const bool b_xlo = __ballot(m_xlo) != 0ull, b_xhi = __ballot(m_xhi) != 0ull;
+    const bool b_ylo = __ballot(m_ylo) != 0ull, b_yhi = __ballot(m_yhi) != 0ull;
+    const bool b00 = __ballot(c00) != 0ull, b01 = __ballot(c01) != 0ull;
+    const bool b10 = __ballot(c10) != 0ull, b11 = __ballot(c11) != 0ull;
+    const bool b_first = __ballot(first_col) != 0ull, b_last = __ballot(last_col) != 0ull;
+    if (lane == 0) {
+      const int64_t X = tx, Y = ty;
+      if (b_xlo) tile_activate(g, w, X - 1, Y, round + 1);
+      if (b_xhi) tile_activate(g, w, X + 1, Y, round + 1);
+      if (b_ylo) tile_activate(g, w, X, Y - 1, round + 1);
+      if (b_yhi) tile_activate(g, w, X, Y + 1, round + 1);
+      if (b00) tile_activate(g, w, X - 1, Y - 1, round + 1);
+      if (b01) tile_activate(g, w, X - 1, Y + 1, round + 1);
+      if (b10) tile_activate(g, w, X + 1, Y - 1, round + 1);
+      if (b11) tile_activate(g, w, X + 1, Y + 1, round + 1);
+      if (b_first) w.status[2] = 1;
+      if (b_last) w.status[3] = 1;
+      atomicAdd(&w.status[0], 1u);
+      atomicAdd(&w.status[1], sweeps);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -238,110 +324,95 @@ __global__ void k_fill_inf(double* p, uint64_t n) {
     p[i] = __longlong_as_double(0x7FF0000000000000ll);
 }
 
-__global__ void k_seed_goal(WaveGrid g, WaveQueues q, uint32_t cell) {
-  g.cost[cell] = 0.0;
-  wave_push(q, cell, 0.0);
+// The goal is inserted without check_node (astar.rs:155): cost 0 even on an obstacle or border.
+__global__ void k_seed_goal(TileGrid g, TileWork w) {
+  g.cost[g.goal_cell] = 0.0;
+  const uint64_t lx = (uint64_t)g.goal_cell / g.yw, y = (uint64_t)g.goal_cell - lx * g.yw;
+  tile_activate(g, w, (int64_t)((lx - g.own_lo) / kTile), (int64_t)(y / kTile), 0);
 }
 
-// Halo columns handed in by the neighbours: where the new value is lower than the stored one,
-// store it and list the cell as a seed; track the lowest / highest seed bucket.
-__global__ void k_take_halo(WaveGrid g, const double* __restrict__ lo_new,
-                            const double* __restrict__ hi_new, uint32_t* seed_cell,
-                            uint32_t* seed_count, uint32_t* seed_range) {
-  uint32_t y = blockIdx.x * blockDim.x + threadIdx.x;
+// Halo columns handed in by the neighbour ranks: where the new value is lower than the stored one,
+// store it and wake the tiles whose ring contains the cell.
+__global__ void k_take_halo(TileGrid g, TileWork w, const double* __restrict__ lo_new,
+                            const double* __restrict__ hi_new) {
+  const uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (y >= g.yw) return;
   for (int side = 0; side < 2; ++side) {
     const double* src = side ? hi_new : lo_new;
     if (!src) continue;
-    uint32_t cell = (side ? (g.ncols - 1) : 0u) * g.yw + y;
-    double v = src[y];
+    const uint64_t col = side ? g.own_hi : g.own_lo - 1;
+    const uint64_t cell = col * g.yw + y;
+    const double v = src[y];
     if (v < g.cost[cell]) {
       g.cost[cell] = v;
-      uint32_t slot = atomicAdd(seed_count, 1u);
-      seed_cell[slot] = cell;
-      double fb = floor(v);
-      uint32_t b = fb < 4.0e9 ? (uint32_t)fb : 0xFFFFFFFEu;
-      atomicMin(&seed_range[0], b);
-      atomicMax(&seed_range[1], b);
+      // an owned tile column holds `col` itself when the owned width is not a multiple of the
+      // tile size; otherwise the last tile column sees it in its ring
+      const int64_t tx = side ? (int64_t)g.ntx - 1 : 0;
+      const int64_t ty = (int64_t)(y / kTile);
+      tile_activate(g, w, tx, ty, 0);
+      if (y % kTile == 0) tile_activate(g, w, tx, ty - 1, 0);
+      if (y % kTile == kTile - 1) tile_activate(g, w, tx, ty + 1, 0);
     }
   }
 }
 
-struct WaveWork {
-  WaveQueues q{};
-  uint32_t* seed_cell = nullptr;
-  uint32_t* seed_count = nullptr;  // [0] count, [1] min bucket, [2] max bucket
-  void* base = nullptr;
+struct TileRun {
+  TileWork w{};
+  uint32_t ntiles = 0;
 };
 
-int32_t wave_alloc(pp_ctx* ctx, uint64_t ncells, uint32_t yw, uint32_t cap, WaveWork* w) {
-  uint32_t nb = (uint32_t)std::min<uint64_t>(ncells + 16, (uint64_t)1 << 26);
-  size_t sz = 0;
-  auto take = [&](size_t bytes) {
-    size_t o = sz;
-    sz += (bytes + 255) & ~(size_t)255;
-    return o;
-  };
-  size_t o_cell[3], o_cost[3];
-  for (int i = 0; i < 3; ++i) {
-    o_cell[i] = take((size_t)cap * 4);
-    o_cost[i] = take((size_t)cap * 8);
+// Work lists live in a context-owned buffer (grown on demand) so repeated calls do not allocate.
+int32_t tile_prepare(pp_ctx* ctx, TileGrid& g, TileRun* run) {
+  g.ntx = (uint32_t)((g.own_hi - g.own_lo + kTile - 1) / kTile);
+  g.nty = (uint32_t)((g.yw + kTile - 1) / kTile);
+  const uint64_t ntiles = (uint64_t)g.ntx * g.nty;
+  if (ntiles == 0 || ntiles >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
+  const size_t arr = ((size_t)ntiles * 4 + 255) & ~(size_t)255;
+  const size_t need = 4 * arr + 256;
+  if (need > ctx->wave_bytes) {
+    if (ctx->wave_buf) PP_HIP(ctx, hipFree(ctx->wave_buf));
+    ctx->wave_buf = nullptr;
+    ctx->wave_bytes = 0;
+    PP_HIP(ctx, hipMalloc(&ctx->wave_buf, need));
+    ctx->wave_bytes = need;
   }
-  size_t o_cnt = take((size_t)nb * 4), o_st = take(64), o_seed = take((size_t)2 * yw * 4 + 16), o_sc = take(64);
-  PP_HIP(ctx, hipMalloc(&w->base, sz));
-  char* b = (char*)w->base;
-  for (int i = 0; i < 3; ++i) {
-    w->q.cell[i] = (uint32_t*)(b + o_cell[i]);
-    w->q.qcost[i] = (double*)(b + o_cost[i]);
-  }
-  w->q.cap = cap;
-  w->q.count = (uint32_t*)(b + o_cnt);
-  w->q.nbuckets = nb;
-  w->q.status = (uint32_t*)(b + o_st);
-  w->seed_cell = (uint32_t*)(b + o_seed);
-  w->seed_count = (uint32_t*)(b + o_sc);
-  w->q.seed_cell = w->seed_cell;
-  w->q.seed_count = nullptr;
-  PP_HIP(ctx, hipMemsetAsync(w->q.count, 0, (size_t)nb * 4, ctx->stream));
-  PP_HIP(ctx, hipMemsetAsync(w->q.status, 0, 64, ctx->stream));
-  uint32_t sc[3] = {0u, 0xFFFFFFFFu, 0u};
-  PP_HIP(ctx, hipMemcpyAsync(w->seed_count, sc, 12, hipMemcpyHostToDevice, ctx->stream));
+  char* b = (char*)ctx->wave_buf;
+  run->ntiles = (uint32_t)ntiles;
+  run->w.list[0] = (uint32_t*)b;
+  run->w.list[1] = (uint32_t*)(b + arr);
+  run->w.flag[0] = (uint32_t*)(b + 2 * arr);
+  run->w.flag[1] = (uint32_t*)(b + 3 * arr);
+  run->w.count = (uint32_t*)(b + 4 * arr);
+  run->w.status = (uint32_t*)(b + 4 * arr + 64);
+  PP_HIP(ctx, hipMemsetAsync(b + 2 * arr, 0, 2 * arr + 256, ctx->stream));
   return PP_OK;
 }
 
-// Runs bucket steps from k0 until no bucket at or above the current one holds work.
-int32_t wave_run(pp_ctx* ctx, const WaveGrid& g, WaveWork& w, uint32_t k0, uint32_t seed_max,
-                 uint64_t* iters, uint32_t status_out[4]) {
+// Rounds until no tile is listed.  The host looks at the list length once per batch of rounds;
+// a round over an empty list costs one empty launch.
+int32_t tile_run(pp_ctx* ctx, const TileGrid& g, TileRun& run, uint64_t* rounds_out,
+                 uint32_t status_out[4]) {
   const double diag = std::hypot(1.0, 1.0);  // u_cost((+-1, +-1)), astar.rs:213-215
-  const unsigned block = 256;
-  const unsigned grid = (unsigned)ctx->num_cus * 4;
-  uint32_t k = k0;
-  uint32_t st[4] = {0, 0, 0, 0};
-  uint64_t steps = 0;
-  const uint32_t batch = 128;
+  const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus * 3,
+                                                     (run.ntiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  uint32_t round = 0;
+  uint32_t counts[3];
+  uint32_t batch = 8;
   for (;;) {
-    for (uint32_t j = 0; j < batch; ++j, ++k) {
-      if (k >= w.q.nbuckets) break;
-      hipLaunchKernelGGL(k_wave_step, dim3(grid), dim3(block), 0, ctx->stream, g, w.q, k, diag);
-      ++steps;
-    }
+    for (uint32_t j = 0; j < batch; ++j, ++round)
+      hipLaunchKernelGGL(k_tile_round, dim3(grid), dim3(64 * kWavesPerBlock), 0, ctx->stream, g, run.w,
+                         round, diag);
     PP_HIP(ctx, hipGetLastError());
-    PP_HIP(ctx, hipMemcpyAsync(st, w.q.status, 16, hipMemcpyDeviceToHost, ctx->stream));
+    PP_HIP(ctx, hipMemcpyAsync(counts, run.w.count, 12, hipMemcpyDeviceToHost, ctx->stream));
     PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (st[1]) break;  // overflow
-    uint32_t last = std::max(st[0], seed_max);
-    if (k > last || k >= w.q.nbuckets) break;
+    if (counts[round % 3] == 0) break;
+    if (round > (1u << 30)) return PP_ERR_UNSUPPORTED;
+    batch = std::min<uint32_t>(batch * 2, 64);
   }
-  if (iters) *iters = steps;
-  std::memcpy(status_out, st, sizeof(st));
-  if (st[1] & 2u) return PP_ERR_UNSUPPORTED;  // cost beyond the bucket table
-  if (st[1] & 1u) return PP_ERR_CAPACITY;
+  PP_HIP(ctx, hipMemcpyAsync(status_out, run.w.status, 16, hipMemcpyDeviceToHost, ctx->stream));
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (rounds_out) *rounds_out = round;
   return PP_OK;
-}
-
-uint32_t queue_cap_guess(uint64_t xw, uint64_t yw) {
-  uint64_t c = 64 * (xw + yw) + (1u << 16);
-  return (uint32_t)std::min<uint64_t>(c, xw * yw + 16);
 }
 
 }  // namespace
@@ -352,27 +423,18 @@ extern "C" int32_t pp_wavefront_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const
                                     uint64_t goal_x, uint64_t goal_y, double* d_cost,
                                     uint64_t* iters) {
   if (!ctx || !d_obs || !d_cost) return PP_ERR_INVALID;
-  if (xw == 0 || yw == 0 || xw * yw >= ((uint64_t)1 << 32) || yw >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
+  if (xw == 0 || yw == 0 || xw >= ((uint64_t)1 << 31) || yw >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
   // the goal's own hmap write (astar.rs:195) indexes hmap[gx - minx][gy - miny]
   if (goal_x >= xw || goal_y >= yw) return PP_ERR_BOUNDS;
   PP_HIP(ctx, hipSetDevice(ctx->device));
-  uint64_t ncells = xw * yw;
-  WaveGrid g{d_cost, d_obs, (uint32_t)yw, (uint32_t)xw, 0, (int64_t)xw, 0u, (uint32_t)xw};
-  uint32_t cap = queue_cap_guess(xw, yw);
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    WaveWork w;
-    int32_t st = wave_alloc(ctx, ncells, (uint32_t)yw, cap, &w);
-    if (st != PP_OK) return st;
-    hipLaunchKernelGGL(k_fill_inf, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, d_cost, ncells);
-    hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, g, w.q,
-                       (uint32_t)(goal_x * yw + goal_y));
-    uint32_t status[4];
-    st = wave_run(ctx, g, w, 0, 0, iters, status);
-    (void)hipFree(w.base);
-    if (st != PP_ERR_CAPACITY) return st;
-    cap = (uint32_t)std::min<uint64_t>(ncells + 16, 0xFFFFFFF0u);  // frontier larger than guessed
-  }
-  return PP_ERR_CAPACITY;
+  TileGrid g{d_cost, d_obs, yw, xw, 0, (int64_t)xw, 0, xw, 0, 0, (int64_t)(goal_x * yw + goal_y)};
+  TileRun run;
+  int32_t st = tile_prepare(ctx, g, &run);
+  if (st != PP_OK) return st;
+  hipLaunchKernelGGL(k_fill_inf, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, d_cost, xw * yw);
+  hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, g, run.w);
+  uint32_t status[4];
+  return tile_run(ctx, g, run, iters, status);
 }
 
 extern "C" int32_t pp_wavefront_slab_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, uint64_t x_begin,
@@ -383,36 +445,24 @@ extern "C" int32_t pp_wavefront_slab_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, 
                                          int32_t* changed_hi, uint64_t* iters) {
   if (!ctx || !d_obs_slab || !d_cost_slab) return PP_ERR_INVALID;
   if (x_begin >= x_end || x_end > xw) return PP_ERR_INVALID;
-  uint64_t ncols = x_end - x_begin + 2;
-  if (ncols * yw >= ((uint64_t)1 << 32) || yw >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
+  if (yw == 0 || xw >= ((uint64_t)1 << 31) || yw >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
   if (seed_goal && (goal_x >= xw || goal_y >= yw)) return PP_ERR_BOUNDS;
   PP_HIP(ctx, hipSetDevice(ctx->device));
-  WaveGrid g{d_cost_slab, d_obs_slab, (uint32_t)yw, (uint32_t)ncols, (int64_t)x_begin - 1,
-             (int64_t)xw, 1u, (uint32_t)(ncols - 1)};
-  uint32_t cap = queue_cap_guess(ncols, yw);
-  WaveWork w;
-  int32_t st = wave_alloc(ctx, ncols * yw, (uint32_t)yw, cap, &w);
+  const uint64_t ncols = x_end - x_begin + 2;
+  const bool goal_here = seed_goal && goal_x >= x_begin && goal_x < x_end;
+  TileGrid g{d_cost_slab, d_obs_slab, yw, ncols, (int64_t)x_begin - 1, (int64_t)xw, 1, ncols - 1, 0, 0,
+             goal_x >= x_begin && goal_x < x_end ? (int64_t)((goal_x - x_begin + 1) * yw + goal_y) : -1};
+  TileRun run;
+  int32_t st = tile_prepare(ctx, g, &run);
   if (st != PP_OK) return st;
-  hipLaunchKernelGGL(k_take_halo, dim3((unsigned)((yw + 255) / 256)), dim3(256), 0, ctx->stream, g,
-                     d_halo_lo_new, d_halo_hi_new, w.seed_cell, w.seed_count, w.seed_count + 1);
-  bool goal_here = seed_goal && goal_x >= x_begin && goal_x < x_end;
-  if (goal_here)
-    hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, g, w.q,
-                       (uint32_t)((goal_x - x_begin + 1) * yw + goal_y));
-  uint32_t sc[3];
-  PP_HIP(ctx, hipMemcpyAsync(sc, w.seed_count, 12, hipMemcpyDeviceToHost, ctx->stream));
-  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (d_halo_lo_new || d_halo_hi_new)
+    hipLaunchKernelGGL(k_take_halo, dim3((unsigned)((yw + 255) / 256)), dim3(256), 0, ctx->stream, g,
+                       run.w, d_halo_lo_new, d_halo_hi_new);
+  if (goal_here) hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, g, run.w);
   uint32_t status[4] = {0, 0, 0, 0};
-  uint64_t steps = 0;
-  if (sc[0] > 0 || goal_here) {
-    uint32_t k0 = goal_here ? 0u : sc[1];
-    w.q.seed_count = w.seed_count;
-    st = wave_run(ctx, g, w, k0, sc[0] ? sc[2] : 0u, &steps, status);
-  }
-  (void)hipFree(w.base);
+  st = tile_run(ctx, g, run, iters, status);
   if (changed_lo) *changed_lo = (int32_t)status[2];
   if (changed_hi) *changed_hi = (int32_t)status[3];
-  if (iters) *iters = steps;
   return st;
 }
 

@@ -65,6 +65,9 @@ struct pp_ctx {
   // reusable device scratch (grown on demand, never shrunk)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // work lists of the heuristic relaxation (grown on demand, never shrunk)
+  void* wave_buf = nullptr;
+  size_t wave_bytes = 0;
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
 };

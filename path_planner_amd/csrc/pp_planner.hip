@@ -611,7 +611,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       stats[i].closed_order = co;
     }
     if (status) status[i] = q.status;
-    if (q.status < 0 && ret == PP_OK) ret = q.status;
+    if (q.status < 0 && ret == PP_OK && !status) ret = q.status;  // per-query codes go to status[]
   }
   return ret;
 }

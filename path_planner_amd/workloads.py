@@ -119,3 +119,43 @@ def rs_pairs(n, seed=SEED_RS, start=0, extent=100.0):
 
 def demo_maxc():
     return math.tan(0.6) / 3.5
+
+
+def plan_map(size=4096, density=0.006, seed=SEED_PLAN):
+    """size x size raster occ[y, x] for the many-queries workload: border + sparse clustered
+    obstacles (thin wall segments 8..40 cells long, random orientation) up to `density`."""
+    occ = np.zeros((size, size), np.uint8)
+    n_seg = int(size * size * density / 24.0)
+    u = uniform01(seed, 0, 4 * n_seg).reshape(n_seg, 4)
+    cx = (u[:, 0] * (size - 80)).astype(np.int64) + 40
+    cy = (u[:, 1] * (size - 80)).astype(np.int64) + 40
+    ln = (u[:, 2] * 33).astype(np.int64) + 8
+    horiz = u[:, 3] < 0.5
+    for x, y, l, h in zip(cx, cy, ln, horiz):
+        if h:
+            occ[y, x:x + l] = 1
+        else:
+            occ[y:y + l, x] = 1
+    occ[0, :] = occ[-1, :] = 1
+    occ[:, 0] = occ[:, -1] = 1
+    return occ
+
+
+def plan_queries(n, size=4096, n_goals=64, seed=SEED_PLAN + 1, min_dist=30.0, max_dist=200.0):
+    """n candidate (start, goal) pose pairs; query i aims at goal i % n_goals and starts
+    min_dist..max_dist away from it.  Returns (starts[n,3], goals[n,3]); the caller drops
+    candidates whose start or goal pose collides."""
+    ug = uniform01(seed, 0, 3 * n_goals).reshape(n_goals, 3)
+    pool = np.empty((n_goals, 3))
+    pool[:, 0] = 260.0 + ug[:, 0] * (size - 520.0)
+    pool[:, 1] = 260.0 + ug[:, 1] * (size - 520.0)
+    pool[:, 2] = ug[:, 2] * (2 * math.pi) - math.pi
+    us = uniform01(seed + 1, 0, 3 * n).reshape(n, 3)
+    goals = pool[np.arange(n) % n_goals]
+    r = min_dist + us[:, 0] * (max_dist - min_dist)
+    a = us[:, 1] * (2 * math.pi)
+    starts = np.empty((n, 3))
+    starts[:, 0] = goals[:, 0] + r * np.cos(a)
+    starts[:, 1] = goals[:, 1] + r * np.sin(a)
+    starts[:, 2] = us[:, 2] * (2 * math.pi) - math.pi
+    return starts, goals.copy()

@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--map", type=int, default=4096, help="queries workload map edge")
     ap.add_argument("--goals", type=int, default=64, help="distinct goals the queries share")
     ap.add_argument("--max-expansions", type=int, default=3000)
+    ap.add_argument("--band", type=float, default=0.0, help="relaxation band override (wavefront)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
     return ap.parse_args()
@@ -90,6 +91,8 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx = api.Context(local_rank, stream.cuda_stream)
     conf = A.demo_config()
+    if args.band > 0:
+        assert ctx.lib.pp_ctx_set_relax_band(ctx.h, args.band) == 0
 
     def barrier():
         torch.cuda.synchronize()
@@ -241,8 +244,10 @@ def main():
             "rs_paths": int(sum(stt[i].rs_paths for i in range(nq))),
             "t_heuristic_ms": float(stt[0].t_heuristic_ms), "t_search_ms": float(stt[0].t_search_ms),
             "note": "counters of rank 0's shard, last step"}
-    if args.workload == "wavefront" and world > 1:
-        out["config"]["exchange_rounds"] = rounds[-1]
+    if args.workload == "wavefront":
+        out["config"]["relaxation"] = api.wavefront_stats(ctx)
+        if world > 1:
+            out["config"]["exchange_rounds"] = rounds[-1]
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -127,6 +127,8 @@ def load_library(path=None):
         "pp_last_hip_error": (C.c_int32, [vp]),
         "pp_version": (C.c_char_p, []),
         "pp_ctx_set_max_expansions": (C.c_int32, [vp, C.c_uint64]),
+        "pp_wavefront_stats": (C.c_int32, [vp, c_u64_p]),
+        "pp_ctx_set_relax_band": (C.c_int32, [vp, C.c_double]),
         "pp_map_create": (C.c_int32, [vp, d, d, C.c_uint64, C.POINTER(vp)]),
         "pp_map_create_raster": (C.c_int32, [vp, u8, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64,
                                              C.POINTER(vp)]),

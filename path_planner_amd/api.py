@@ -194,6 +194,12 @@ def wavefront_dev(ctx, obs, goal_x, goal_y, cost):
     return iters.value
 
 
+def wavefront_stats(ctx):
+    out = np.zeros(4, np.uint64)
+    _chk(ctx.lib.pp_wavefront_stats(ctx.h, _p(out, C.c_uint64)), "pp_wavefront_stats")
+    return dict(zip(("rounds", "tile_visits", "sweep_pairs", "tiles"), (int(v) for v in out)))
+
+
 # ------------------------------------------------------------------ Reeds-Shepp
 def _cols(q):
     q = _f64(q).reshape(-1, 3)

@@ -69,6 +69,12 @@ extern "C" int32_t pp_ctx_synchronize(pp_ctx* ctx) {
   return PP_OK;
 }
 
+extern "C" int32_t pp_ctx_set_relax_band(pp_ctx* ctx, double band) {
+  if (!ctx || !(band >= 0.0)) return PP_ERR_INVALID;
+  ctx->wave_band = band;
+  return PP_OK;
+}
+
 extern "C" int32_t pp_ctx_set_max_expansions(pp_ctx* ctx, uint64_t max_expansions) {
   if (!ctx) return PP_ERR_INVALID;
   ctx->max_expansions = max_expansions;

@@ -96,36 +96,68 @@ __global__ void k_obsmap(uint64_t n, const double* __restrict__ ox, const double
 // The reference's Dijkstra (astar.rs:153-198) computes the unique fixpoint of
 //   d[goal] = 0,  d[v] = min over valid neighbours n of fl(d[n] + w(n, v)),  w in {1, hypot(1,1)}
 // (each fl(d + w) is monotone in d, so relaxing from any upper bounds in any order converges to the
-// same bits).  The grid is cut into 32x32-cell tiles; a round relaxes every active tile to its
+// same bits).  The grid is cut into 32x32-cell tiles; a round relaxes every listed tile to its
 // own fixpoint against the current values of the surrounding ring of cells, and a tile whose edge
-// cells moved activates the neighbours that see them.  One wave owns one tile: each lane keeps a
-// 4x4 patch in registers and sweeps it forward and backward (a two-pass chamfer transform), the
-// patches trade edge values through LDS, and the wave repeats until no cell moves.
+// cells moved wakes the neighbours that see them.  One wave owns one tile: each lane keeps a 4x4
+// patch in registers and sweeps it forward and backward (a two-pass chamfer transform), the
+// patches trade rim values through LDS, and the wave repeats until no cell moves.
+//
+// Rounds are ordered by cost, Dijkstra-like at tile granularity: a woken tile carries a key (the
+// lowest value that newly appeared next to it) and is listed only once the key is within `band`
+// of the lowest pending key.  Relaxing a tile before its inputs have settled would push
+// provisional values downstream that every later correction has to chase.
+//
+// Working layout: costs live in a blocked array, one contiguous 8 KiB block per tile with the
+// 16 cells of a lane's patch interleaved across lanes (so every load is a coalesced 1 KiB), and
+// the obstacle raster is folded into one mask word per lane.  The caller's dense x-major arrays
+// are packed into that layout before the rounds and unpacked after them.
 
 constexpr int kTile = 32;                    // cells per tile side
 constexpr int kPps = 8;                      // 4x4 patches per tile side
 constexpr int kRing = kPps + 2;              // patch grid plus the ring outside the tile
-constexpr int kSlot = kRing * kRing;         // doubles per patch-cell slot
-constexpr int kWaveLds = 16 * kSlot;         // doubles of LDS per wave
+constexpr int kSlot = kRing * kRing;         // doubles per rim slot
+constexpr int kWaveLds = 12 * kSlot;         // doubles of LDS per wave: the 12 rim cells of a patch
 constexpr int kWavesPerBlock = 4;
+constexpr int kBlk = kTile * kTile;          // doubles per tile block
+constexpr unsigned long long kInfBits = 0x7FF0000000000000ull;
 
-struct TileGrid {
+// LDS slot of patch cell (i, j); only cells on the patch rim are ever read by other lanes.
+__device__ constexpr int rim_slot(int i, int j) {
+  return i == 0 ? j : (i == 3 ? 4 + j : (j == 0 ? 7 + i : 9 + i));
+}
+__device__ constexpr bool on_rim(int i, int j) { return i == 0 || i == 3 || j == 0 || j == 3; }
+// Offset of patch cell k = 4i + j of `lane` inside a tile block: cells 2m, 2m+1 of one lane are
+// adjacent (one 16-byte access), the 64 lanes of a pair are consecutive.
+__device__ __host__ constexpr uint32_t blk_off(uint32_t k, uint32_t lane) {
+  return ((k >> 1) * 64u + lane) * 2u + (k & 1u);
+}
+
+struct DenseView {       // the caller's arrays
   double* cost;          // cost[lx * yw + y]: x-major, one x-column of yw cells contiguous
   const uint8_t* obs;    // same indexing
   uint64_t yw;
   uint64_t ncols;        // stored columns (a slab includes its two halo columns)
   int64_t gx_off;        // global x of stored column 0
-  int64_t xw;            // global grid width
   uint64_t own_lo, own_hi;  // stored columns [own_lo, own_hi) are relaxed, the rest only read
-  uint32_t ntx, nty;     // tiles over the owned columns
-  int64_t goal_cell;     // index of the goal cell in cost[], -1 when it is not stored here
+  int64_t goal_x, goal_y;   // stored column / row of the goal, -1 when it is not in an owned column
+};
+
+struct TileGrid {
+  double* blk;           // tile t at blk + t * kBlk
+  uint32_t* mask;        // mask[t * 64 + lane]: bit k = cell k blocked, bit 16 + k = cell k fixed
+  uint32_t ntx, nty;     // tiles over the stored columns
 };
 
 struct TileWork {
-  uint32_t* list[2];     // tiles to relax in even / odd rounds
-  uint32_t* flag[2];     // "already listed" per tile, per parity
+  uint32_t* list;        // tiles to relax this round
+  uint32_t* bitmap;      // woken tiles
   uint32_t* count;       // [3]: list lengths of rounds r, r+1, r+2 (mod 3)
+  unsigned long long* key;      // per tile: bit pattern of the lowest pending value
+  unsigned long long* minkey;   // [3]: lowest pending key for rounds r, r+1, r+2 (mod 3)
   uint32_t* status;      // [0] tile visits, [1] sweep pairs, [2] first owned column moved, [3] last
+  uint32_t ntiles;
+  double band;
+  uint64_t own_first, own_last;  // stored columns whose change is reported in status[2], [3]
 };
 
 __device__ inline double pp_min_f64(double a, double b) {
@@ -139,20 +171,132 @@ __device__ inline double pp_max_f64(double a, double b) {
   return r;
 }
 
-__device__ inline void tile_activate(const TileGrid& g, const TileWork& w, int64_t tx, int64_t ty,
-                                     uint32_t round) {
+// Wakes tile (tx, ty) with key `kbits` (bit patterns of non-negative doubles order like the
+// doubles).  Neither atomic returns a value, so the caller does not wait on them; the caller folds
+// kbits into minkey[] of the next round.
+__device__ inline void tile_wake(const TileGrid& g, const TileWork& w, int64_t tx, int64_t ty,
+                                 unsigned long long kbits) {
   if (tx < 0 || ty < 0 || tx >= (int64_t)g.ntx || ty >= (int64_t)g.nty) return;
   const uint32_t t = (uint32_t)tx * g.nty + (uint32_t)ty;
-  if (atomicExch(&w.flag[round & 1][t], 1u) == 0u) {
-    const uint32_t s = atomicAdd(&w.count[round % 3], 1u);
-    w.list[round & 1][s] = t;
+  atomicMin(&w.key[t], kbits);
+  atomicOr(&w.bitmap[t >> 5], 1u << (t & 31u));
+}
+
+// Address of cell (x, y) (stored column, row) in the blocked array; +inf outside the tile grid.
+__device__ inline double tile_cell_value(const TileGrid& g, int64_t x, int64_t y) {
+  if (x < 0 || y < 0 || x >= (int64_t)g.ntx * kTile || y >= (int64_t)g.nty * kTile)
+    return __longlong_as_double((long long)kInfBits);
+  const uint32_t t = (uint32_t)(x >> 5) * g.nty + (uint32_t)(y >> 5);
+  const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
+  return g.blk[(uint64_t)t * kBlk + blk_off((lx & 3u) * 4u + (ly & 3u), (lx >> 2) * 8u + (ly >> 2))];
+}
+
+// Dense -> blocked.  One wave per tile, consecutive waves take tiles that are consecutive in y so
+// the strided rows of the dense arrays are read in long runs.
+__global__ void __launch_bounds__(256)
+k_tile_pack(DenseView d, TileGrid g, uint32_t ntiles, int init_inf) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t px = lane >> 3, py = lane & 7u;
+  const double INF = __longlong_as_double((long long)kInfBits);
+  for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * 4) {
+    const uint32_t tx = t / g.nty, ty = t - tx * g.nty;
+    uint32_t m = 0;
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t x = (int64_t)tx * kTile + 4 * px + i, y = (int64_t)ty * kTile + 4 * py + j;
+        const int k = i * 4 + j;
+        v[k] = INF;
+        if (x < (int64_t)d.ncols && y < (int64_t)d.yw) {
+          const uint64_t idx = (uint64_t)x * d.yw + (uint64_t)y;
+          if (!init_inf) v[k] = d.cost[idx];
+          if (x < (int64_t)d.own_lo || x >= (int64_t)d.own_hi) {
+            m |= 1u << (16 + k);  // another rank's column: a source, never relaxed here
+          } else {
+            // check_node (astar.rs:200-211); the goal is inserted without it (astar.rs:155)
+            const bool blocked = d.obs[idx] != 0 || x + d.gx_off <= 0 || y <= 0;
+            if (blocked && !(x == d.goal_x && y == d.goal_y)) m |= 1u << k;
+          }
+        } else {
+          m |= 1u << k;
+        }
+      }
+    }
+    double* b = g.blk + (uint64_t)t * kBlk;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2)
+      *(double2*)(b + blk_off(2 * k2, lane)) = make_double2(v[2 * k2], v[2 * k2 + 1]);
+    g.mask[(uint64_t)t * 64 + lane] = m;
   }
 }
 
-__device__ inline double tile_ring_value(const TileGrid& g, int64_t x, int64_t y) {
-  if (x < 0 || y < 0 || x >= (int64_t)g.ncols || y >= (int64_t)g.yw)
-    return __longlong_as_double(0x7FF0000000000000ll);
-  return g.cost[(uint64_t)x * g.yw + (uint64_t)y];
+// Blocked -> dense, owned and halo columns alike.
+__global__ void __launch_bounds__(256) k_tile_unpack(DenseView d, TileGrid g, uint32_t ntiles) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t px = lane >> 3, py = lane & 7u;
+  for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * 4) {
+    const uint32_t tx = t / g.nty, ty = t - tx * g.nty;
+    const double* b = g.blk + (uint64_t)t * kBlk;
+    double v[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const double2 p = *(const double2*)(b + blk_off(2 * k2, lane));
+      v[2 * k2] = p.x;
+      v[2 * k2 + 1] = p.y;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t x = (int64_t)tx * kTile + 4 * px + i, y = (int64_t)ty * kTile + 4 * py + j;
+        if (x < (int64_t)d.ncols && y < (int64_t)d.yw) d.cost[(uint64_t)x * d.yw + (uint64_t)y] = v[i * 4 + j];
+      }
+    }
+  }
+}
+
+// Lists the woken tiles whose key is within the band of the lowest pending key; the others stay
+// woken and their keys go into the next round's minimum.  One lane per tile, so the key loads of
+// a crowded stretch of the bitmap are all in flight together.
+__global__ void __launch_bounds__(256) k_tile_list(TileGrid g, TileWork w, uint32_t round) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const double theta = __longlong_as_double((long long)w.minkey[round % 3]) + w.band;
+  if (t == 0) {
+    w.count[(round + 1) % 3] = 0;
+    w.minkey[(round + 2) % 3] = kInfBits;
+  }
+  const uint32_t word = t < w.ntiles ? w.bitmap[t >> 5] : 0u;
+  const bool woken = (word >> (t & 31u)) & 1u;
+  if (__ballot(woken) == 0ull) return;  // wave-uniform
+  bool take = false;
+  unsigned long long kb = kInfBits;
+  if (woken) {
+    kb = w.key[t];
+    take = !(__longlong_as_double((long long)kb) > theta);
+  }
+  // the 32 lanes that share a bitmap word clear their taken bits together
+  const unsigned long long tb = __ballot(take);
+  if ((lane & 31u) == 0u) {
+    const uint32_t cleared = (uint32_t)(tb >> (lane & 32u));
+    if (cleared) w.bitmap[t >> 5] = word & ~cleared;
+  }
+  if (take) w.key[t] = kInfBits;
+  const uint32_t ntake = (uint32_t)__popcll(tb);
+  uint32_t base = 0;
+  if (lane == 0 && ntake) base = atomicAdd(&w.count[round % 3], ntake);
+  base = __shfl(base, 0);
+  if (take) w.list[base + (uint32_t)__popcll(tb & ((1ull << lane) - 1ull))] = t;
+  // keys left waiting
+  unsigned long long wait = (woken && !take) ? kb : kInfBits;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(wait, off);
+    wait = o < wait ? o : wait;
+  }
+  if (lane == 0 && wait != kInfBits) atomicMin(&w.minkey[(round + 1) % 3], wait);
 }
 
 __global__ void __launch_bounds__(64 * kWavesPerBlock)
@@ -161,57 +305,55 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   double* lds = lds_all + wv * kWaveLds;
   const uint32_t n = w.count[round % 3];
-  if (blockIdx.x == 0 && threadIdx.x == 0) w.count[(round + 2) % 3] = 0;
-  const uint32_t* list = w.list[round & 1];
   const int px = (int)(lane >> 3), py = (int)(lane & 7u);
-  const double INF = __longlong_as_double(0x7FF0000000000000ll);
+  const double INF = __longlong_as_double((long long)kInfBits);
   const int own_slot = (px + 1) * kRing + (py + 1);
+  unsigned long long wave_min = kInfBits;  // lowest key this wave handed out
+  uint32_t visits = 0, sweeps_total = 0;
 
   for (uint32_t it = blockIdx.x * kWavesPerBlock + wv; it < n; it += gridDim.x * kWavesPerBlock) {
-    const uint32_t t = list[it];
-    if (lane == 0) w.flag[round & 1][t] = 0;
+    const uint32_t t = w.list[it];
     const uint32_t tx = t / g.nty, ty = t - tx * g.nty;
-    const int64_t x0 = (int64_t)g.own_lo + (int64_t)tx * kTile, y0 = (int64_t)ty * kTile;
+    const int64_t x0 = (int64_t)tx * kTile, y0 = (int64_t)ty * kTile;
+    double* blk = g.blk + (uint64_t)t * kBlk;
 
     // e[1..4][1..4] = the lane's patch, the rest of e = the cells around it.  floor_[][] is the
-    // value a cell may not go below: 0 for a free cell, +inf for a blocked one (check_node,
-    // astar.rs:200-211), its own value for a stored cell this rank does not own.
+    // value a cell may not go below: 0 for a free cell, +inf for a blocked one, its own value for
+    // a cell that is only a source.
     double e[6][6], floor_[4][4];
+    const uint32_t m = g.mask[(uint64_t)t * 64 + lane];
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const double2 p = *(const double2*)(blk + blk_off(2 * k2, lane));
+      e[(2 * k2) / 4 + 1][(2 * k2) % 4 + 1] = p.x;
+      e[(2 * k2 + 1) / 4 + 1][(2 * k2 + 1) % 4 + 1] = p.y;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int64_t x = x0 + 4 * px + i, y = y0 + 4 * py + j;
-        double v = INF, fl = INF;
-        if (x < (int64_t)g.ncols && y < (int64_t)g.yw) {
-          const uint64_t idx = (uint64_t)x * g.yw + (uint64_t)y;
-          v = g.cost[idx];
-          if (x >= (int64_t)g.own_hi) {
-            fl = v;
-          } else {
-            const bool blocked = g.obs[idx] != 0 || x + g.gx_off <= 0 || y <= 0;
-            fl = (blocked && (int64_t)idx != g.goal_cell) ? INF : 0.0;
-          }
-        }
-        e[i + 1][j + 1] = v;
-        floor_[i][j] = fl;
-        lds[(i * 4 + j) * kSlot + own_slot] = v;
+        const int k = i * 4 + j;
+        const double v = e[i + 1][j + 1];
+        floor_[i][j] = ((m >> k) & 1u) ? INF : (((m >> (16 + k)) & 1u) ? v : 0.0);
+        if (on_rim(i, j)) lds[rim_slot(i, j) * kSlot + own_slot] = v;
       }
     }
     // the ring of cells just outside the tile
     if (lane < 34) {
       const int o = (int)lane - 1, q = (o + 4) >> 2, j = (o + 4) & 3;
-      lds[(3 * 4 + j) * kSlot + 0 * kRing + q] = tile_ring_value(g, x0 - 1, y0 + o);
-      lds[(0 * 4 + j) * kSlot + (kRing - 1) * kRing + q] = tile_ring_value(g, x0 + kTile, y0 + o);
+      lds[(4 + j) * kSlot + 0 * kRing + q] = tile_cell_value(g, x0 - 1, y0 + o);            // slot (3, j)
+      lds[j * kSlot + (kRing - 1) * kRing + q] = tile_cell_value(g, x0 + kTile, y0 + o);    // slot (0, j)
     }
     if (lane < 32) {
       const int o = (int)lane, prow = (o >> 2) + 1, i = o & 3;
-      lds[(i * 4 + 3) * kSlot + prow * kRing + 0] = tile_ring_value(g, x0 + o, y0 - 1);
-      lds[(i * 4 + 0) * kSlot + prow * kRing + (kRing - 1)] = tile_ring_value(g, x0 + o, y0 + kTile);
+      const int s3 = i == 0 ? 3 : (i == 3 ? 7 : 9 + i), s0 = i == 0 ? 0 : (i == 3 ? 4 : 7 + i);
+      lds[s3 * kSlot + prow * kRing + 0] = tile_cell_value(g, x0 + o, y0 - 1);                  // slot (i, 3)
+      lds[s0 * kSlot + prow * kRing + (kRing - 1)] = tile_cell_value(g, x0 + o, y0 + kTile);    // slot (i, 0)
     }
 
     uint32_t sweeps = 0;
     for (;;) {
+      const double in11 = e[2][2], in12 = e[2][3], in21 = e[3][2], in22 = e[3][3];
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -221,7 +363,7 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
           if (ii >= 1 && ii <= 4 && jj >= 1 && jj <= 4) continue;
           const int dx = ii == 0 ? -1 : (ii == 5 ? 1 : 0), dy = jj == 0 ? -1 : (jj == 5 ? 1 : 0);
           const int si = ii == 0 ? 3 : (ii == 5 ? 0 : ii - 1), sj = jj == 0 ? 3 : (jj == 5 ? 0 : jj - 1);
-          e[ii][jj] = lds[(si * 4 + sj) * kSlot + own_slot + dx * kRing + dy];
+          e[ii][jj] = lds[rim_slot(si, sj) * kSlot + own_slot + dx * kRing + dy];
         }
       }
 #pragma unroll
@@ -250,12 +392,16 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      bool moved = false;
+      bool moved = __double_as_longlong(in11) != __double_as_longlong(e[2][2]) ||
+                   __double_as_longlong(in12) != __double_as_longlong(e[2][3]) ||
+                   __double_as_longlong(in21) != __double_as_longlong(e[3][2]) ||
+                   __double_as_longlong(in22) != __double_as_longlong(e[3][3]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          double* slot = &lds[(i * 4 + j) * kSlot + own_slot];
+          if (!on_rim(i, j)) continue;
+          double* slot = &lds[rim_slot(i, j) * kSlot + own_slot];
           const double v = e[i + 1][j + 1];
           moved |= __double_as_longlong(*slot) != __double_as_longlong(v);
           *slot = v;
@@ -268,107 +414,122 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
     // write back what moved; cells on the tile's edge wake the neighbours that read them
     bool m_xlo = false, m_xhi = false, m_ylo = false, m_yhi = false;
     bool c00 = false, c01 = false, c10 = false, c11 = false, first_col = false, last_col = false;
+    double edge_min = INF;  // lowest value that moved on the tile's edge
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int k2 = 0; k2 < 8; ++k2) {
+      double2* p = (double2*)(blk + blk_off(2 * k2, lane));
+      const double2 old = *p;
+      bool any = false;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int li = 4 * px + i, lj = 4 * py + j;
-        const int64_t x = x0 + li, y = y0 + lj;
-        if (x < (int64_t)g.own_hi && y < (int64_t)g.yw) {
-          const uint64_t idx = (uint64_t)x * g.yw + (uint64_t)y;
-          const double v = e[i + 1][j + 1];
-          if (__double_as_longlong(g.cost[idx]) != __double_as_longlong(v)) {
-            g.cost[idx] = v;
-            m_xlo |= li == 0;
-            m_xhi |= li == kTile - 1;
-            m_ylo |= lj == 0;
-            m_yhi |= lj == kTile - 1;
-            c00 |= li == 0 && lj == 0;
-            c01 |= li == 0 && lj == kTile - 1;
-            c10 |= li == kTile - 1 && lj == 0;
-            c11 |= li == kTile - 1 && lj == kTile - 1;
-            first_col |= x == (int64_t)g.own_lo;
-            last_col |= x + 1 == (int64_t)g.own_hi;
-          }
+      for (int h = 0; h < 2; ++h) {
+        const int k = 2 * k2 + h, i = k / 4, j = k % 4;
+        const double v = e[i + 1][j + 1];
+        if (__double_as_longlong(h ? old.y : old.x) != __double_as_longlong(v)) {
+          any = true;
+          const int li = 4 * px + i, lj = 4 * py + j;
+          if (li == 0 || li == kTile - 1 || lj == 0 || lj == kTile - 1) edge_min = pp_min_f64(edge_min, v);
+          m_xlo |= li == 0;
+          m_xhi |= li == kTile - 1;
+          m_ylo |= lj == 0;
+          m_yhi |= lj == kTile - 1;
+          c00 |= li == 0 && lj == 0;
+          c01 |= li == 0 && lj == kTile - 1;
+          c10 |= li == kTile - 1 && lj == 0;
+          c11 |= li == kTile - 1 && lj == kTile - 1;
+          first_col |= (uint64_t)(x0 + li) == w.own_first;
+          last_col |= (uint64_t)(x0 + li) == w.own_last;
         }
       }
+      if (any) *p = make_double2(e[(2 * k2) / 4 + 1][(2 * k2) % 4 + 1], e[(2 * k2 + 1) / 4 + 1][(2 * k2 + 1) % 4 + 1]);
     }
     const bool b_xlo = __ballot(m_xlo) != 0ull, b_xhi = __ballot(m_xhi) != 0ull;
     const bool b_ylo = __ballot(m_ylo) != 0ull, b_yhi = __ballot(m_yhi) != 0ull;
     const bool b00 = __ballot(c00) != 0ull, b01 = __ballot(c01) != 0ull;
     const bool b10 = __ballot(c10) != 0ull, b11 = __ballot(c11) != 0ull;
     const bool b_first = __ballot(first_col) != 0ull, b_last = __ballot(last_col) != 0ull;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) edge_min = pp_min_f64(edge_min, __shfl_xor(edge_min, off));
+    const unsigned long long ek = (unsigned long long)__double_as_longlong(edge_min);
+    if (b_xlo || b_xhi || b_ylo || b_yhi) wave_min = min(wave_min, ek);
+    // lanes 0..7 wake one neighbour each
+    if (lane < 8) {
+      const int ddx = lane < 3 ? -1 : (lane < 5 ? 0 : 1);
+      const int ddy = (lane == 0 || lane == 3 || lane == 5) ? -1 : ((lane == 2 || lane == 4 || lane == 7) ? 1 : 0);
+      const bool wake = lane == 0 ? b00 : lane == 1 ? b_xlo : lane == 2 ? b01 : lane == 3 ? b_ylo
+                      : lane == 4 ? b_yhi : lane == 5 ? b10 : lane == 6 ? b_xhi : b11;
+      if (wake) tile_wake(g, w, (int64_t)tx + ddx, (int64_t)ty + ddy, ek);
+    }
     if (lane == 0) {
-      const int64_t X = tx, Y = ty;
-      if (b_xlo) tile_activate(g, w, X - 1, Y, round + 1);
-      if (b_xhi) tile_activate(g, w, X + 1, Y, round + 1);
-      if (b_ylo) tile_activate(g, w, X, Y - 1, round + 1);
-      if (b_yhi) tile_activate(g, w, X, Y + 1, round + 1);
-      if (b00) tile_activate(g, w, X - 1, Y - 1, round + 1);
-      if (b01) tile_activate(g, w, X - 1, Y + 1, round + 1);
-      if (b10) tile_activate(g, w, X + 1, Y - 1, round + 1);
-      if (b11) tile_activate(g, w, X + 1, Y + 1, round + 1);
       if (b_first) w.status[2] = 1;
       if (b_last) w.status[3] = 1;
-      atomicAdd(&w.status[0], 1u);
-      atomicAdd(&w.status[1], sweeps);
     }
+    ++visits;
+    sweeps_total += sweeps;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0 && visits) {
+    if (wave_min != kInfBits) atomicMin(&w.minkey[(round + 1) % 3], wave_min);
+    atomicAdd(&w.status[0], visits);
+    atomicAdd(&w.status[1], sweeps_total);
   }
 }
 
 __global__ void k_fill_inf(double* p, uint64_t n) {
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    p[i] = __longlong_as_double(0x7FF0000000000000ll);
+    p[i] = __longlong_as_double((long long)kInfBits);
 }
 
 // The goal is inserted without check_node (astar.rs:155): cost 0 even on an obstacle or border.
-__global__ void k_seed_goal(TileGrid g, TileWork w) {
-  g.cost[g.goal_cell] = 0.0;
-  const uint64_t lx = (uint64_t)g.goal_cell / g.yw, y = (uint64_t)g.goal_cell - lx * g.yw;
-  tile_activate(g, w, (int64_t)((lx - g.own_lo) / kTile), (int64_t)(y / kTile), 0);
+__global__ void k_seed_goal(TileGrid g, TileWork w, int64_t x, int64_t y) {
+  const uint32_t t = (uint32_t)(x >> 5) * g.nty + (uint32_t)(y >> 5);
+  const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
+  g.blk[(uint64_t)t * kBlk + blk_off((lx & 3u) * 4u + (ly & 3u), (lx >> 2) * 8u + (ly >> 2))] = 0.0;
+  tile_wake(g, w, x >> 5, y >> 5, 0ull);
+  atomicMin(&w.minkey[0], 0ull);
 }
 
-// Halo columns handed in by the neighbour ranks: where the new value is lower than the stored one,
-// store it and wake the tiles whose ring contains the cell.
-__global__ void k_take_halo(TileGrid g, TileWork w, const double* __restrict__ lo_new,
+// Halo columns handed in by the neighbour ranks (dense arrays, before packing): where the new value
+// is lower than the stored one, store it and wake every tile that holds or borders the cell.
+__global__ void k_take_halo(DenseView d, TileGrid g, TileWork w, const double* __restrict__ lo_new,
                             const double* __restrict__ hi_new) {
   const uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (y >= g.yw) return;
+  if (y >= d.yw) return;
   for (int side = 0; side < 2; ++side) {
     const double* src = side ? hi_new : lo_new;
     if (!src) continue;
-    const uint64_t col = side ? g.own_hi : g.own_lo - 1;
-    const uint64_t cell = col * g.yw + y;
+    const uint64_t col = side ? d.own_hi : d.own_lo - 1;
+    const uint64_t cell = col * d.yw + y;
     const double v = src[y];
-    if (v < g.cost[cell]) {
-      g.cost[cell] = v;
-      // an owned tile column holds `col` itself when the owned width is not a multiple of the
-      // tile size; otherwise the last tile column sees it in its ring
-      const int64_t tx = side ? (int64_t)g.ntx - 1 : 0;
-      const int64_t ty = (int64_t)(y / kTile);
-      tile_activate(g, w, tx, ty, 0);
-      if (y % kTile == 0) tile_activate(g, w, tx, ty - 1, 0);
-      if (y % kTile == kTile - 1) tile_activate(g, w, tx, ty + 1, 0);
+    if (v < d.cost[cell]) {
+      d.cost[cell] = v;
+      const unsigned long long kb = (unsigned long long)__double_as_longlong(v);
+      for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int64_t nx = (int64_t)col + dx, ny = (int64_t)y + dy;
+          if (nx >= 0 && ny >= 0) tile_wake(g, w, nx >> 5, ny >> 5, kb);
+        }
+      atomicMin(&w.minkey[0], kb);
     }
   }
 }
 
 struct TileRun {
+  TileGrid g{};
   TileWork w{};
-  uint32_t ntiles = 0;
 };
 
-// Work lists live in a context-owned buffer (grown on demand) so repeated calls do not allocate.
-int32_t tile_prepare(pp_ctx* ctx, TileGrid& g, TileRun* run) {
-  g.ntx = (uint32_t)((g.own_hi - g.own_lo + kTile - 1) / kTile);
-  g.nty = (uint32_t)((g.yw + kTile - 1) / kTile);
-  const uint64_t ntiles = (uint64_t)g.ntx * g.nty;
+// Blocked costs, masks and work lists live in a context-owned buffer (grown on demand) so
+// repeated calls do not allocate.
+int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run) {
+  const uint64_t ntx = (d.ncols + kTile - 1) / kTile, nty = (d.yw + kTile - 1) / kTile;
+  const uint64_t ntiles = ntx * nty;
   if (ntiles == 0 || ntiles >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
-  const size_t arr = ((size_t)ntiles * 4 + 255) & ~(size_t)255;
-  const size_t need = 4 * arr + 256;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t b_blk = al(ntiles * kBlk * 8), b_mask = al(ntiles * 64 * 4), b_list = al(ntiles * 4);
+  const size_t b_bits = al(((ntiles + 63) / 64) * 8), b_key = al(ntiles * 8), b_misc = 256;
+  const size_t need = b_blk + b_mask + b_list + b_bits + b_key + b_misc;
   if (need > ctx->wave_bytes) {
     if (ctx->wave_buf) PP_HIP(ctx, hipFree(ctx->wave_buf));
     ctx->wave_buf = nullptr;
@@ -377,47 +538,80 @@ int32_t tile_prepare(pp_ctx* ctx, TileGrid& g, TileRun* run) {
     ctx->wave_bytes = need;
   }
   char* b = (char*)ctx->wave_buf;
-  run->ntiles = (uint32_t)ntiles;
-  run->w.list[0] = (uint32_t*)b;
-  run->w.list[1] = (uint32_t*)(b + arr);
-  run->w.flag[0] = (uint32_t*)(b + 2 * arr);
-  run->w.flag[1] = (uint32_t*)(b + 3 * arr);
-  run->w.count = (uint32_t*)(b + 4 * arr);
-  run->w.status = (uint32_t*)(b + 4 * arr + 64);
-  PP_HIP(ctx, hipMemsetAsync(b + 2 * arr, 0, 2 * arr + 256, ctx->stream));
+  run->g.blk = (double*)b;
+  b += b_blk;
+  run->g.mask = (uint32_t*)b;
+  b += b_mask;
+  run->g.ntx = (uint32_t)ntx;
+  run->g.nty = (uint32_t)nty;
+  run->w.list = (uint32_t*)b;
+  b += b_list;
+  run->w.bitmap = (uint32_t*)b;
+  b += b_bits;
+  run->w.key = (unsigned long long*)b;
+  b += b_key;
+  run->w.count = (uint32_t*)b;
+  run->w.status = (uint32_t*)(b + 64);
+  run->w.minkey = (unsigned long long*)(b + 128);
+  run->w.ntiles = (uint32_t)ntiles;
+  run->w.band = ctx->wave_band;
+  run->w.own_first = d.own_lo;
+  run->w.own_last = d.own_hi - 1;
+  PP_HIP(ctx, hipMemsetAsync(run->w.bitmap, 0, b_bits, ctx->stream));
+  PP_HIP(ctx, hipMemsetAsync(run->w.count, 0, 128, ctx->stream));
+  // keys and minkey[3] start at +inf
+  hipLaunchKernelGGL(k_fill_inf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, (double*)run->w.key,
+                     (uint64_t)ntiles);
+  hipLaunchKernelGGL(k_fill_inf, dim3(1), dim3(64), 0, ctx->stream, (double*)run->w.minkey, (uint64_t)3);
   return PP_OK;
 }
 
-// Rounds until no tile is listed.  The host looks at the list length once per batch of rounds;
-// a round over an empty list costs one empty launch.
-int32_t tile_run(pp_ctx* ctx, const TileGrid& g, TileRun& run, uint64_t* rounds_out,
-                 uint32_t status_out[4]) {
+// Rounds until no tile is woken.  The host looks at the list length once per batch of rounds; a
+// round over an empty list costs two empty launches.
+int32_t tile_run(pp_ctx* ctx, TileRun& run, uint64_t* rounds_out, uint32_t status_out[4]) {
   const double diag = std::hypot(1.0, 1.0);  // u_cost((+-1, +-1)), astar.rs:213-215
-  const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus * 3,
-                                                     (run.ntiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus * 4,
+                                                     (run.w.ntiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  const unsigned lgrid = (run.w.ntiles + 255) / 256;
   uint32_t round = 0;
   uint32_t counts[3];
   uint32_t batch = 8;
   for (;;) {
-    for (uint32_t j = 0; j < batch; ++j, ++round)
-      hipLaunchKernelGGL(k_tile_round, dim3(grid), dim3(64 * kWavesPerBlock), 0, ctx->stream, g, run.w,
-                         round, diag);
+    for (uint32_t j = 0; j < batch; ++j, ++round) {
+      hipLaunchKernelGGL(k_tile_list, dim3(lgrid), dim3(256), 0, ctx->stream, run.g, run.w, round);
+      hipLaunchKernelGGL(k_tile_round, dim3(grid), dim3(64 * kWavesPerBlock), 0, ctx->stream, run.g,
+                         run.w, round, diag);
+    }
     PP_HIP(ctx, hipGetLastError());
     PP_HIP(ctx, hipMemcpyAsync(counts, run.w.count, 12, hipMemcpyDeviceToHost, ctx->stream));
     PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (counts[round % 3] == 0) break;
+    if (counts[(round - 1) % 3] == 0) break;  // the last round found nothing woken
     if (round > (1u << 30)) return PP_ERR_UNSUPPORTED;
     batch = std::min<uint32_t>(batch * 2, 64);
   }
   PP_HIP(ctx, hipMemcpyAsync(status_out, run.w.status, 16, hipMemcpyDeviceToHost, ctx->stream));
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (rounds_out) *rounds_out = round;
+  ctx->wave_stats[0] = round;
+  ctx->wave_stats[1] = status_out[0];
+  ctx->wave_stats[2] = status_out[1];
+  ctx->wave_stats[3] = run.w.ntiles;
   return PP_OK;
+}
+
+unsigned tile_stream_grid(const pp_ctx* ctx, uint32_t ntiles) {
+  return (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus * 8, ((uint64_t)ntiles + 3) / 4);
 }
 
 }  // namespace
 
 // ---------------------------------------------------------------------------- entry points
+
+extern "C" int32_t pp_wavefront_stats(pp_ctx* ctx, uint64_t out[4]) {
+  if (!ctx || !out) return PP_ERR_INVALID;
+  std::memcpy(out, ctx->wave_stats, sizeof(ctx->wave_stats));
+  return PP_OK;
+}
 
 extern "C" int32_t pp_wavefront_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint8_t* d_obs,
                                     uint64_t goal_x, uint64_t goal_y, double* d_cost,
@@ -427,14 +621,20 @@ extern "C" int32_t pp_wavefront_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const
   // the goal's own hmap write (astar.rs:195) indexes hmap[gx - minx][gy - miny]
   if (goal_x >= xw || goal_y >= yw) return PP_ERR_BOUNDS;
   PP_HIP(ctx, hipSetDevice(ctx->device));
-  TileGrid g{d_cost, d_obs, yw, xw, 0, (int64_t)xw, 0, xw, 0, 0, (int64_t)(goal_x * yw + goal_y)};
+  DenseView d{d_cost, d_obs, yw, xw, 0, 0, xw, (int64_t)goal_x, (int64_t)goal_y};
   TileRun run;
-  int32_t st = tile_prepare(ctx, g, &run);
+  int32_t st = tile_prepare(ctx, d, &run);
   if (st != PP_OK) return st;
-  hipLaunchKernelGGL(k_fill_inf, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, d_cost, xw * yw);
-  hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, g, run.w);
+  const unsigned sg = tile_stream_grid(ctx, run.w.ntiles);
+  hipLaunchKernelGGL(k_tile_pack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.w.ntiles, 1);
+  hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, run.g, run.w, (int64_t)goal_x,
+                     (int64_t)goal_y);
   uint32_t status[4];
-  return tile_run(ctx, g, run, iters, status);
+  st = tile_run(ctx, run, iters, status);
+  if (st != PP_OK) return st;
+  hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.w.ntiles);
+  PP_HIP(ctx, hipGetLastError());
+  return PP_OK;
 }
 
 extern "C" int32_t pp_wavefront_slab_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, uint64_t x_begin,
@@ -449,21 +649,28 @@ extern "C" int32_t pp_wavefront_slab_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, 
   if (seed_goal && (goal_x >= xw || goal_y >= yw)) return PP_ERR_BOUNDS;
   PP_HIP(ctx, hipSetDevice(ctx->device));
   const uint64_t ncols = x_end - x_begin + 2;
-  const bool goal_here = seed_goal && goal_x >= x_begin && goal_x < x_end;
-  TileGrid g{d_cost_slab, d_obs_slab, yw, ncols, (int64_t)x_begin - 1, (int64_t)xw, 1, ncols - 1, 0, 0,
-             goal_x >= x_begin && goal_x < x_end ? (int64_t)((goal_x - x_begin + 1) * yw + goal_y) : -1};
+  const bool goal_owned = goal_x >= x_begin && goal_x < x_end && goal_y < yw;
+  DenseView d{d_cost_slab, d_obs_slab, yw, ncols, (int64_t)x_begin - 1, 1, ncols - 1,
+              goal_owned ? (int64_t)(goal_x - x_begin + 1) : -1, goal_owned ? (int64_t)goal_y : -1};
   TileRun run;
-  int32_t st = tile_prepare(ctx, g, &run);
+  int32_t st = tile_prepare(ctx, d, &run);
   if (st != PP_OK) return st;
   if (d_halo_lo_new || d_halo_hi_new)
-    hipLaunchKernelGGL(k_take_halo, dim3((unsigned)((yw + 255) / 256)), dim3(256), 0, ctx->stream, g,
-                       run.w, d_halo_lo_new, d_halo_hi_new);
-  if (goal_here) hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, g, run.w);
+    hipLaunchKernelGGL(k_take_halo, dim3((unsigned)((yw + 255) / 256)), dim3(256), 0, ctx->stream, d,
+                       run.g, run.w, d_halo_lo_new, d_halo_hi_new);
+  const unsigned sg = tile_stream_grid(ctx, run.w.ntiles);
+  hipLaunchKernelGGL(k_tile_pack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.w.ntiles, 0);
+  if (seed_goal && goal_owned)
+    hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, run.g, run.w, d.goal_x, d.goal_y);
   uint32_t status[4] = {0, 0, 0, 0};
-  st = tile_run(ctx, g, run, iters, status);
+  st = tile_run(ctx, run, iters, status);
+  if (st != PP_OK) return st;
+  hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.w.ntiles);
+  PP_HIP(ctx, hipGetLastError());
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (changed_lo) *changed_lo = (int32_t)status[2];
   if (changed_hi) *changed_hi = (int32_t)status[3];
-  return st;
+  return PP_OK;
 }
 
 // calc_parameters of astar.rs:232-242 on the obstacle lists scaled by 1/reso.

@@ -140,7 +140,26 @@ struct DenseView {       // the caller's arrays
   int64_t gx_off;        // global x of stored column 0
   uint64_t own_lo, own_hi;  // stored columns [own_lo, own_hi) are relaxed, the rest only read
   int64_t goal_x, goal_y;   // stored column / row of the goal, -1 when it is not in an owned column
+  // Several independent grids over the same obstacle raster, relaxed together: plane p occupies
+  // stored columns [p * plane_cols, p * plane_cols + plane_cols - 1) followed by one blocked
+  // separator column, its costs start at cost + p * cost_stride and its goal is goals[2p], [2p+1].
+  uint32_t planes;          // 0: a single grid, none of the fields below is used
+  uint64_t plane_cols;
+  uint64_t cost_stride;
+  const int64_t* goals;
 };
+
+// Stored column -> (plane, column inside the plane's dense arrays); false for a separator column.
+__device__ inline bool dense_column(const DenseView& d, int64_t x, uint32_t& plane, int64_t& xl) {
+  if (d.planes == 0) {
+    plane = 0;
+    xl = x;
+    return true;
+  }
+  plane = (uint32_t)((uint64_t)x / d.plane_cols);
+  xl = x - (int64_t)(plane * d.plane_cols);
+  return xl + 1 < (int64_t)d.plane_cols;
+}
 
 struct TileGrid {
   double* blk;           // tile t at blk + t * kBlk
@@ -209,15 +228,19 @@ k_tile_pack(DenseView d, TileGrid g, uint32_t ntiles, int init_inf) {
         const int64_t x = (int64_t)tx * kTile + 4 * px + i, y = (int64_t)ty * kTile + 4 * py + j;
         const int k = i * 4 + j;
         v[k] = INF;
-        if (x < (int64_t)d.ncols && y < (int64_t)d.yw) {
-          const uint64_t idx = (uint64_t)x * d.yw + (uint64_t)y;
-          if (!init_inf) v[k] = d.cost[idx];
+        uint32_t plane;
+        int64_t xl;
+        if (x < (int64_t)d.ncols && y < (int64_t)d.yw && dense_column(d, x, plane, xl)) {
+          const uint64_t idx = (uint64_t)xl * d.yw + (uint64_t)y;
+          if (!init_inf) v[k] = d.cost[plane * d.cost_stride + idx];
           if (x < (int64_t)d.own_lo || x >= (int64_t)d.own_hi) {
             m |= 1u << (16 + k);  // another rank's column: a source, never relaxed here
           } else {
             // check_node (astar.rs:200-211); the goal is inserted without it (astar.rs:155)
-            const bool blocked = d.obs[idx] != 0 || x + d.gx_off <= 0 || y <= 0;
-            if (blocked && !(x == d.goal_x && y == d.goal_y)) m |= 1u << k;
+            const bool blocked = d.obs[idx] != 0 || xl + d.gx_off <= 0 || y <= 0;
+            const int64_t gx = d.planes ? d.goals[2 * plane] : d.goal_x;
+            const int64_t gy = d.planes ? d.goals[2 * plane + 1] : d.goal_y;
+            if (blocked && !(xl == gx && y == gy)) m |= 1u << k;
           }
         } else {
           m |= 1u << k;
@@ -251,7 +274,10 @@ __global__ void __launch_bounds__(256) k_tile_unpack(DenseView d, TileGrid g, ui
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int64_t x = (int64_t)tx * kTile + 4 * px + i, y = (int64_t)ty * kTile + 4 * py + j;
-        if (x < (int64_t)d.ncols && y < (int64_t)d.yw) d.cost[(uint64_t)x * d.yw + (uint64_t)y] = v[i * 4 + j];
+        uint32_t plane;
+        int64_t xl;
+        if (x < (int64_t)d.ncols && y < (int64_t)d.yw && dense_column(d, x, plane, xl))
+          d.cost[plane * d.cost_stride + (uint64_t)xl * d.yw + (uint64_t)y] = v[i * 4 + j];
       }
     }
   }
@@ -490,6 +516,18 @@ __global__ void k_seed_goal(TileGrid g, TileWork w, int64_t x, int64_t y) {
   atomicMin(&w.minkey[0], 0ull);
 }
 
+__global__ void k_seed_goals(TileGrid g, TileWork w, uint32_t planes, uint64_t plane_cols,
+                             const int64_t* __restrict__ goals) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= planes) return;
+  const int64_t x = (int64_t)(p * plane_cols) + goals[2 * p], y = goals[2 * p + 1];
+  const uint32_t t = (uint32_t)(x >> 5) * g.nty + (uint32_t)(y >> 5);
+  const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
+  g.blk[(uint64_t)t * kBlk + blk_off((lx & 3u) * 4u + (ly & 3u), (lx >> 2) * 8u + (ly >> 2))] = 0.0;
+  tile_wake(g, w, x >> 5, y >> 5, 0ull);
+  if (p == 0) atomicMin(&w.minkey[0], 0ull);
+}
+
 // Halo columns handed in by the neighbour ranks (dense arrays, before packing): where the new value
 // is lower than the stored one, store it and wake every tile that holds or borders the cell.
 __global__ void k_take_halo(DenseView d, TileGrid g, TileWork w, const double* __restrict__ lo_new,
@@ -621,7 +659,7 @@ extern "C" int32_t pp_wavefront_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const
   // the goal's own hmap write (astar.rs:195) indexes hmap[gx - minx][gy - miny]
   if (goal_x >= xw || goal_y >= yw) return PP_ERR_BOUNDS;
   PP_HIP(ctx, hipSetDevice(ctx->device));
-  DenseView d{d_cost, d_obs, yw, xw, 0, 0, xw, (int64_t)goal_x, (int64_t)goal_y};
+  DenseView d{d_cost, d_obs, yw, xw, 0, 0, xw, (int64_t)goal_x, (int64_t)goal_y, 0, 0, 0, nullptr};
   TileRun run;
   int32_t st = tile_prepare(ctx, d, &run);
   if (st != PP_OK) return st;
@@ -634,6 +672,51 @@ extern "C" int32_t pp_wavefront_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const
   if (st != PP_OK) return st;
   hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.w.ntiles);
   PP_HIP(ctx, hipGetLastError());
+  return PP_OK;
+}
+
+// n grids over one obstacle raster, one goal each, relaxed in the same rounds (the planner's
+// heuristic maps for the distinct goal cells of a batch of queries).  d_cost holds the n dense
+// grids cost_stride doubles apart; goal_x / goal_y are host arrays.
+int32_t pp_wavefront_multi_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint8_t* d_obs, uint32_t n,
+                               const uint64_t* goal_x, const uint64_t* goal_y, double* d_cost,
+                               uint64_t cost_stride) {
+  if (!ctx || !d_obs || !d_cost || !goal_x || !goal_y) return PP_ERR_INVALID;
+  if (n == 0) return PP_OK;
+  if (xw == 0 || yw == 0 || xw >= ((uint64_t)1 << 31) || yw >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  // planes per pass: keep the blocked working copy under ~8 GiB
+  const uint64_t plane_tiles = ((xw + 1 + kTile - 1) / kTile + 1) * ((yw + kTile - 1) / kTile);
+  const uint32_t per_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, ((uint64_t)1 << 20) / plane_tiles));
+  std::vector<int64_t> hg(2 * (size_t)per_pass);
+  for (uint32_t p0 = 0; p0 < n; p0 += per_pass) {
+    const uint32_t np = std::min(per_pass, n - p0);
+    for (uint32_t p = 0; p < np; ++p) {
+      if (goal_x[p0 + p] >= xw || goal_y[p0 + p] >= yw) return PP_ERR_BOUNDS;
+      hg[2 * p] = (int64_t)goal_x[p0 + p];
+      hg[2 * p + 1] = (int64_t)goal_y[p0 + p];
+    }
+    int32_t st = pp_scratch_reserve(ctx, 2 * (size_t)per_pass * 8);
+    if (st != PP_OK) return st;
+    int64_t* d_goals = (int64_t*)ctx->scratch;
+    PP_HIP(ctx, hipMemcpyAsync(d_goals, hg.data(), 2 * (size_t)np * 8, hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t ncols = (uint64_t)np * (xw + 1);
+    DenseView d{d_cost + (uint64_t)p0 * cost_stride, d_obs, yw, ncols, 0, 0, ncols, -1, -1,
+                np, xw + 1, cost_stride, d_goals};
+    TileRun run;
+    st = tile_prepare(ctx, d, &run);
+    if (st != PP_OK) return st;
+    const unsigned sg = tile_stream_grid(ctx, run.w.ntiles);
+    hipLaunchKernelGGL(k_tile_pack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.w.ntiles, 1);
+    hipLaunchKernelGGL(k_seed_goals, dim3((np + 63) / 64), dim3(64), 0, ctx->stream, run.g, run.w, np,
+                       xw + 1, (const int64_t*)d_goals);
+    uint32_t status[4];
+    st = tile_run(ctx, run, nullptr, status);
+    if (st != PP_OK) return st;
+    hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.w.ntiles);
+    PP_HIP(ctx, hipGetLastError());
+    PP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // d_goals is reused by the next pass
+  }
   return PP_OK;
 }
 
@@ -651,7 +734,8 @@ extern "C" int32_t pp_wavefront_slab_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, 
   const uint64_t ncols = x_end - x_begin + 2;
   const bool goal_owned = goal_x >= x_begin && goal_x < x_end && goal_y < yw;
   DenseView d{d_cost_slab, d_obs_slab, yw, ncols, (int64_t)x_begin - 1, 1, ncols - 1,
-              goal_owned ? (int64_t)(goal_x - x_begin + 1) : -1, goal_owned ? (int64_t)goal_y : -1};
+              goal_owned ? (int64_t)(goal_x - x_begin + 1) : -1, goal_owned ? (int64_t)goal_y : -1,
+              0, 0, 0, nullptr};
   TileRun run;
   int32_t st = tile_prepare(ctx, d, &run);
   if (st != PP_OK) return st;

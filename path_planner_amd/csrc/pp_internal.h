@@ -102,6 +102,9 @@ struct pp_map {
   } while (0)
 
 int32_t pp_scratch_reserve(pp_ctx* ctx, size_t bytes);
+int32_t pp_wavefront_multi_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint8_t* d_obs, uint32_t n,
+                               const uint64_t* goal_x, const uint64_t* goal_y, double* d_cost,
+                               uint64_t cost_stride);
 int32_t pp_pinned_reserve(pp_ctx* ctx, size_t bytes);
 PpFootprint pp_make_footprint(const pp_config* conf);
 int32_t pp_check_config(const pp_config* conf);

@@ -167,6 +167,13 @@ struct PinBuf {
   }
 };
 
+__global__ void k_gather_hmap(uint32_t n, const double* const* __restrict__ tab,
+                              const int32_t* __restrict__ slot, const uint64_t* __restrict__ off,
+                              double* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = tab[slot[i]][off[i]];
+}
+
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -236,12 +243,15 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     PP_HIP(ctx, hipMalloc(&tab_buf.p, ngoals * sizeof(double*)));
     st = pp_obsmap_dev(ctx, map, xyreso, 1.0, dims, (uint8_t*)obs_buf.p);
     if (st != PP_OK) return st;
+    std::vector<uint64_t> ggx(ngoals), ggy(ngoals);
     for (size_t g = 0; g < ngoals; ++g) {
       hm_ptr[g] = (double*)((char*)hm_buf.p + g * al256(hcells * 8));
-      st = pp_wavefront_dev(ctx, hxw, hyw, (const uint8_t*)obs_buf.p, goal_cells[g].first,
-                            goal_cells[g].second, hm_ptr[g], nullptr);
-      if (st != PP_OK) return st;
+      ggx[g] = goal_cells[g].first;
+      ggy[g] = goal_cells[g].second;
     }
+    st = pp_wavefront_multi_dev(ctx, hxw, hyw, (const uint8_t*)obs_buf.p, (uint32_t)ngoals, ggx.data(),
+                                ggy.data(), (double*)hm_buf.p, al256(hcells * 8) / 8);
+    if (st != PP_OK) return st;
     PP_HIP(ctx, hipMemcpyAsync(tab_buf.p, hm_ptr.data(), ngoals * sizeof(double*), hipMemcpyHostToDevice, s));
     PP_HIP(ctx, hipStreamSynchronize(s));
   }
@@ -249,7 +259,10 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
 
   // ---- start nodes (hybrid_astar.rs:103-154)
   {
-    // hmap values under the start cells: one small gather per query
+    std::vector<SNode> sn(nq);
+    std::vector<int32_t> g_slot;
+    std::vector<uint64_t> g_off;
+    std::vector<uint32_t> g_q;
     for (uint64_t i = 0; i < nq; ++i) {
       Query& q = Q[i];
       if (!q.live) continue;
@@ -272,9 +285,32 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         q.live = false;
         continue;
       }
-      double h = 0.0;
-      PP_HIP(ctx, hipMemcpy(&h, hm_ptr[q.hmap_slot] + hx * hyw + hy, 8, hipMemcpyDeviceToHost));
-      double f = n.cost + conf->h_cost * h;
+      sn[i] = n;
+      g_slot.push_back(q.hmap_slot);
+      g_off.push_back(hx * hyw + hy);
+      g_q.push_back((uint32_t)i);
+    }
+    // hmap values under the start cells: one gather for all queries
+    const size_t ng = g_q.size();
+    std::vector<double> hval(ng);
+    if (ng) {
+      const size_t b4 = al256(ng * 4), b8 = al256(ng * 8);
+      st = pp_scratch_reserve(ctx, b4 + 2 * b8);
+      if (st != PP_OK) return st;
+      char* b = (char*)ctx->scratch;
+      PP_HIP(ctx, hipMemcpyAsync(b, g_slot.data(), ng * 4, hipMemcpyHostToDevice, s));
+      PP_HIP(ctx, hipMemcpyAsync(b + b4, g_off.data(), ng * 8, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(k_gather_hmap, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
+                         (const double* const*)tab_buf.p, (const int32_t*)b, (const uint64_t*)(b + b4),
+                         (double*)(b + b4 + b8));
+      PP_HIP(ctx, hipGetLastError());
+      PP_HIP(ctx, hipMemcpyAsync(hval.data(), b + b4 + b8, ng * 8, hipMemcpyDeviceToHost, s));
+      PP_HIP(ctx, hipStreamSynchronize(s));
+    }
+    for (size_t k = 0; k < ng; ++k) {
+      Query& q = Q[g_q[k]];
+      const SNode& n = sn[g_q[k]];
+      double f = n.cost + conf->h_cost * hval[k];
       if (f != f) {
         q.status = PP_ERR_NAN_COST;
         q.live = false;
@@ -504,103 +540,165 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   }
   const double t_search = now_ms();
 
-  // ---- extract_path (hybrid_astar.rs:218-250) for the queries that found one
+  // ---- extract_path (hybrid_astar.rs:218-250) for the queries that found one: the analytic
+  // shots' trajectories and the rollout lists of every node on a final path are regenerated in
+  // two batched launches.
   int32_t ret = PP_OK;
+  struct Found {
+    uint32_t q;
+    std::vector<int32_t> chain;  // final RS node's parent <- ... <- start
+    bool with_final;
+    uint32_t nroll, roll0;       // rollout lists used, first one's index in the batch
+  };
+  std::vector<Found> found;
+  std::vector<double> in5;
   for (uint64_t i = 0; i < nq; ++i) {
     Query& q = Q[i];
-    pp_path& po = out[i];
-    po.len = 0;
-    po.cost = 0.0;
-    if (q.found) {
-      // chain: final RS node <- n_curr <- ... <- start
-      std::vector<int32_t> chain;
-      for (int32_t id = q.final_parent; id >= 0; id = q.nodes[id].parent) chain.push_back(id);
-      // chain.back() is the start node
-      const SNode& fp = q.nodes[q.final_parent];
-      double qq[6] = {fp.x, fp.y, fp.yaw, q.goal[0], q.goal[1], q.goal[2]};
-      int32_t np = 0;
-      pp_rs_word words[PP_RS_MAX_PATHS];
-      uint64_t toff[PP_RS_MAX_PATHS + 1];
-      size_t cap_rs = 1 << 16;
-      std::vector<double> rx(cap_rs), ry(cap_rs), ryaw(cap_rs);
-      std::vector<int64_t> rdir(cap_rs);
-      int32_t s2 = pp_rs_single(ctx, qq, maxc, conf->move_step, q.final_rs_idx, &np, words, toff,
-                                rx.data(), ry.data(), ryaw.data(), rdir.data(), cap_rs, nullptr);
-      if (s2 != PP_OK) {
-        q.status = s2;
-      } else {
-        uint64_t a = toff[q.final_rs_idx], b = toff[q.final_rs_idx + 1];
-        q.st.rs_final_length = words[q.final_rs_idx].total_length;
-        // The reference walks `while node.pind >= 0` with pind an isize copy of the parent's
-        // key (:226, :372): a key that wrapped below zero (yaw index under minyaw, the rollout
-        // never wraps yaw) ends the walk early and the start point is appended regardless.
-        const bool with_final =
-            (int64_t)calc_index(fp.xind, fp.yind, fp.yawind, P) >= 0;
-        uint32_t nroll = 0, nlist = 0;
-        if (with_final)
-          while (nroll + 1 < chain.size() && q.nodes[chain[nroll]].pind >= 0) ++nroll;
-        std::vector<double> in5((size_t)nroll * 5);
-        for (uint32_t k = 0; k < nroll; ++k) {
-          const SNode& n = q.nodes[chain[k]];
-          const SNode& pa = q.nodes[n.parent];
-          in5[k * 5 + 0] = pa.x;
-          in5[k * 5 + 1] = pa.y;
-          in5[k * 5 + 2] = pa.yaw;
-          in5[k * 5 + 3] = n.steer;
-          in5[k * 5 + 4] = plan.motion[NP + n.prim];
-        }
-        uint32_t pts = plan.prm.nlist + 1;
-        std::vector<double> lx((size_t)nroll * pts), ly(lx.size()), lyaw(lx.size());
-        s2 = pp_rollout_points_batch(ctx, conf, nroll, in5.data(), lx.data(), ly.data(), lyaw.data(), &nlist);
-        if (s2 != PP_OK) {
-          q.status = s2;
-        } else {
-          // reversed accumulation exactly as the reference builds it, then one final reverse
-          std::vector<double> X, Y, YAW;
-          std::vector<int64_t> D;
-          double cost = 0.0;
-          if (with_final) {
-            for (uint64_t j = b; j-- > a + 1;) {  // node.x[1..].rev() of the RS node
-              X.push_back(rx[j]);
-              Y.push_back(ry[j]);
-              YAW.push_back(ryaw[j]);
-              D.push_back(rdir[j]);
-            }
-            cost += fp.cost + q.final_rs_cost;  // fcost = n_curr.cost + rs cost (:357)
-          }
-          for (uint32_t k = 0; k < nroll; ++k) {
-            const SNode& n = q.nodes[chain[k]];
-            for (uint32_t j = pts; j-- > 1;) {
-              X.push_back(lx[(size_t)k * pts + j]);
-              Y.push_back(ly[(size_t)k * pts + j]);
-              YAW.push_back(lyaw[(size_t)k * pts + j]);
-              D.push_back(n.direction);
-            }
-            cost += n.cost;
-          }
-          const SNode& ns = q.nodes[chain.back()];
-          X.push_back(ns.x);
-          Y.push_back(ns.y);
-          YAW.push_back(ns.yaw);
-          D.push_back(1);
-          cost += ns.cost;
-          po.len = X.size();
-          po.cost = cost;
-          if (po.cap < X.size() || !po.x || !po.y || !po.yaw || !po.direction) {
-            q.status = PP_ERR_CAPACITY;
-          } else {
-            size_t L = X.size();
-            for (size_t j = 0; j < L; ++j) {
-              po.x[j] = X[L - 1 - j];
-              po.y[j] = Y[L - 1 - j];
-              po.yaw[j] = YAW[L - 1 - j];
-              po.direction[j] = D[L - 1 - j];
-            }
-            q.status = PP_OK;
-          }
+    out[i].len = 0;
+    out[i].cost = 0.0;
+    if (!q.found) continue;
+    Found f;
+    f.q = (uint32_t)i;
+    for (int32_t id = q.final_parent; id >= 0; id = q.nodes[id].parent) f.chain.push_back(id);
+    const SNode& fp = q.nodes[q.final_parent];
+    // The reference walks `while node.pind >= 0` with pind an isize copy of the parent's key
+    // (:226, :372): a key that wrapped below zero (yaw index under minyaw, the rollout never wraps
+    // yaw) ends the walk early and the start point is appended regardless.
+    f.with_final = (int64_t)calc_index(fp.xind, fp.yind, fp.yawind, P) >= 0;
+    f.nroll = 0;
+    if (f.with_final)
+      while (f.nroll + 1 < f.chain.size() && q.nodes[f.chain[f.nroll]].pind >= 0) ++f.nroll;
+    f.roll0 = (uint32_t)(in5.size() / 5);
+    for (uint32_t k = 0; k < f.nroll; ++k) {
+      const SNode& n = q.nodes[f.chain[k]];
+      const SNode& pa = q.nodes[n.parent];
+      in5.insert(in5.end(), {pa.x, pa.y, pa.yaw, n.steer, plan.motion[NP + n.prim]});
+    }
+    found.push_back(std::move(f));
+  }
+  const uint32_t nf = (uint32_t)found.size();
+  const uint32_t pts = plan.prm.nlist + 1;
+  const uint32_t nroll_all = (uint32_t)(in5.size() / 5);
+  std::vector<double> lx((size_t)nroll_all * pts), ly(lx.size()), lyaw(lx.size());
+  if (nroll_all) {
+    uint32_t nlist = 0;
+    st = pp_rollout_points_batch(ctx, conf, nroll_all, in5.data(), lx.data(), ly.data(), lyaw.data(), &nlist);
+    if (st != PP_OK) return st;
+  }
+  // analytic-shot trajectories; windows that turn out too small are redone with the size needed
+  uint32_t cap_rs = 1024;
+  std::vector<double> rx, ry, ryaw, rtotal(nf);
+  std::vector<int64_t> rdir;
+  std::vector<uint32_t> rnp(nf), rfl(nf);
+  std::vector<uint32_t> rcap(nf, 0);       // window size each query's trajectory was written with
+  std::vector<size_t> rbase(nf, 0);
+  {
+    std::vector<uint32_t> todo(nf);
+    for (uint32_t k = 0; k < nf; ++k) todo[k] = k;
+    while (!todo.empty()) {
+      const uint32_t n = (uint32_t)todo.size();
+      std::vector<double> q6((size_t)6 * n);
+      std::vector<int32_t> sel(n);
+      for (uint32_t k = 0; k < n; ++k) {
+        const Query& q = Q[found[todo[k]].q];
+        const SNode& fp = q.nodes[q.final_parent];
+        q6[k] = fp.x;
+        q6[n + k] = fp.y;
+        q6[2 * (size_t)n + k] = fp.yaw;
+        q6[3 * (size_t)n + k] = q.goal[0];
+        q6[4 * (size_t)n + k] = q.goal[1];
+        q6[5 * (size_t)n + k] = q.goal[2];
+        sel[k] = q.final_rs_idx;
+      }
+      const size_t base = rx.size();
+      rx.resize(base + (size_t)n * cap_rs);
+      ry.resize(rx.size());
+      ryaw.resize(rx.size());
+      rdir.resize(rx.size());
+      std::vector<uint32_t> np(n), fl(n);
+      std::vector<double> tot(n);
+      st = pp_rs_selected_batch(ctx, n, q6.data(), maxc, conf->move_step, sel.data(), cap_rs, np.data(),
+                                tot.data(), fl.data(), rx.data() + base, ry.data() + base,
+                                ryaw.data() + base, rdir.data() + base);
+      if (st != PP_OK) return st;
+      std::vector<uint32_t> again;
+      uint32_t need = 0;
+      for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t id = todo[k];
+        rnp[id] = np[k];
+        rfl[id] = fl[k];
+        rtotal[id] = tot[k];
+        rcap[id] = cap_rs;
+        rbase[id] = base + (size_t)k * cap_rs;
+        if (np[k] > cap_rs) {
+          again.push_back(id);
+          need = std::max(need, np[k]);
         }
       }
+      todo.swap(again);
+      cap_rs = need;
     }
+  }
+  for (uint32_t k = 0; k < nf; ++k) {
+    const Found& f = found[k];
+    Query& q = Q[f.q];
+    pp_path& po = out[f.q];
+    if ((rfl[k] & (4u | 8u | 16u)) || rnp[k] == 0) {
+      q.status = PP_ERR_DEGENERATE_RS;
+      continue;
+    }
+    q.st.rs_final_length = rtotal[k];
+    const SNode& fp = q.nodes[q.final_parent];
+    // reversed accumulation exactly as the reference builds it, then one final reverse
+    std::vector<double> X, Y, YAW;
+    std::vector<int64_t> D;
+    double cost = 0.0;
+    if (f.with_final) {
+      const size_t a = rbase[k];
+      for (uint64_t j = rnp[k]; j-- > 1;) {  // node.x[1..].rev() of the RS node
+        X.push_back(rx[a + j]);
+        Y.push_back(ry[a + j]);
+        YAW.push_back(ryaw[a + j]);
+        D.push_back(rdir[a + j]);
+      }
+      cost += fp.cost + q.final_rs_cost;  // fcost = n_curr.cost + rs cost (:357)
+    }
+    for (uint32_t r = 0; r < f.nroll; ++r) {
+      const SNode& n = q.nodes[f.chain[r]];
+      const size_t a = (size_t)(f.roll0 + r) * pts;
+      for (uint32_t j = pts; j-- > 1;) {
+        X.push_back(lx[a + j]);
+        Y.push_back(ly[a + j]);
+        YAW.push_back(lyaw[a + j]);
+        D.push_back(n.direction);
+      }
+      cost += n.cost;
+    }
+    const SNode& ns = q.nodes[f.chain.back()];
+    X.push_back(ns.x);
+    Y.push_back(ns.y);
+    YAW.push_back(ns.yaw);
+    D.push_back(1);
+    cost += ns.cost;
+    po.len = X.size();
+    po.cost = cost;
+    if (po.cap < X.size() || !po.x || !po.y || !po.yaw || !po.direction) {
+      q.status = PP_ERR_CAPACITY;
+    } else {
+      const size_t L = X.size();
+      for (size_t j = 0; j < L; ++j) {
+        po.x[j] = X[L - 1 - j];
+        po.y[j] = Y[L - 1 - j];
+        po.yaw[j] = YAW[L - 1 - j];
+        po.direction[j] = D[L - 1 - j];
+      }
+      q.status = PP_OK;
+    }
+  }
+  const double t_extract = now_ms();
+  (void)t_extract;
+  for (uint64_t i = 0; i < nq; ++i) {
+    Query& q = Q[i];
     q.st.t_heuristic_ms = t_heur - t_begin;
     q.st.t_search_ms = t_search - t_heur;
     if (stats) {

@@ -43,5 +43,10 @@ int32_t pp_rs_single(pp_ctx* ctx, const double q[6], double maxc, double step_si
                      int32_t* n_paths, pp_rs_word* words, uint64_t* traj_off, double* traj_x,
                      double* traj_y, double* traj_yaw, int64_t* traj_dir, uint64_t traj_cap,
                      uint32_t* flags_out);
+// Trajectory of the path with rank sel[i] of each of n pairs (host arrays; q6 = six arrays of n),
+// `cap` points per pair; npts[i] > cap means the window was too small and nothing was written.
+int32_t pp_rs_selected_batch(pp_ctx* ctx, uint32_t n, const double* q6, double maxc, double step_size,
+                             const int32_t* sel, uint32_t cap, uint32_t* npts, double* total,
+                             uint32_t* flags, double* tx, double* ty, double* tyaw, int64_t* tdir);
 
 #endif

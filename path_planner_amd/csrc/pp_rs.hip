@@ -440,6 +440,63 @@ k_rs_traj(double x0, double y0, double yaw0, double maxc, double step_size,
   }
 }
 
+// ------------------------------------------------------------------ one chosen path per pair
+
+// Trajectory of the path with rank sel[pair] (generation order among the accepted words) of each
+// pair, into a fixed window of `cap` points per pair.  One wave per pair.
+__global__ void __launch_bounds__(64)
+k_rs_traj_sel(uint32_t n, const double* __restrict__ sx, const double* __restrict__ sy,
+              const double* __restrict__ syaw, double maxc, double step_size,
+              const PpRsCand* __restrict__ cands, const PpRsPair* __restrict__ pairs,
+              const int32_t* __restrict__ sel, uint32_t cap, uint32_t* __restrict__ npts,
+              double* __restrict__ total, uint32_t* __restrict__ flags, double* __restrict__ tx,
+              double* __restrict__ ty, double* __restrict__ tyaw, int64_t* __restrict__ tdir) {
+  __shared__ PathPlan plan;
+  __shared__ int ok;
+  const uint32_t pair = blockIdx.x;
+  if (pair >= n) return;
+  const int lane = threadIdx.x;
+  if (lane == 0) {
+    const PpRsPair pr = pairs[pair];
+    const int rank = sel[pair];
+    uint32_t fl = pr.flags;
+    ok = 0;
+    npts[pair] = 0;
+    total[pair] = 0.0;
+    if (rank >= 0 && rank < pr.n_paths) {
+      uint64_t m = pr.accepted;
+      for (int k = 0; k < rank; ++k) m &= m - 1;
+      const PpRsCand c = cands[(size_t)pair * PP_RS_MAX_PATHS + __builtin_ctzll(m)];
+      plan_path(c, maxc, step_size * maxc, plan);
+      trim_path(plan, maxc);
+      npts[pair] = (uint32_t)plan.npts;
+      total[pair] = c.total / maxc;  // reeds_shepp.rs:125
+      if (plan.amb) fl |= 2u;
+      if (plan.npts == 0) fl |= 8u;  // px.last().unwrap() on an emptied Vec panics
+      ok = plan.npts > 0 && (uint32_t)plan.npts <= cap;
+    } else {
+      fl |= 16u;
+    }
+    flags[pair] = fl;
+  }
+  __syncthreads();
+  if (!ok) return;
+  const double x0 = sx[pair], y0 = sy[pair], yaw0 = syaw[pair];
+  double s0, c0;
+  sincos(yaw0, &s0, &c0);
+  for (int j = lane; j < plan.npts; j += 64) {
+    double lx, ly, lyaw, X, Y, YAW;
+    int dir;
+    local_point(plan, j, maxc, lx, ly, lyaw, dir);
+    to_global(lx, ly, lyaw, x0, y0, yaw0, c0, s0, X, Y, YAW);
+    const size_t o = (size_t)pair * cap + (size_t)j;
+    tx[o] = X;
+    ty[o] = Y;
+    tyaw[o] = YAW;
+    tdir[o] = dir;
+  }
+}
+
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 PpCostParams cost_params(const pp_config* conf) {
@@ -520,6 +577,49 @@ extern "C" int32_t pp_rs_batch(pp_ctx* ctx, uint64_t n, const double* sx, const 
   PP_HIP(ctx, hipMemcpyAsync(best_idx, d_bi, n * 4, hipMemcpyDeviceToHost, s));
   PP_HIP(ctx, hipMemcpyAsync(best, d_w, n * sizeof(pp_rs_word), hipMemcpyDeviceToHost, s));
   PP_HIP(ctx, hipMemcpyAsync(flags, d_f, n, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipStreamSynchronize(s));
+  return PP_OK;
+}
+
+// The chosen path (rank sel[i]) of n pairs with its trajectory: host in, host out, `cap` points per
+// pair.  flags: the pair's word flags, | 8 trajectory emptied by the trim, | 16 rank out of range.
+int32_t pp_rs_selected_batch(pp_ctx* ctx, uint32_t n, const double* q6 /* 6 arrays of n */, double maxc,
+                             double step_size, const int32_t* sel, uint32_t cap, uint32_t* npts,
+                             double* total, uint32_t* flags, double* tx, double* ty, double* tyaw,
+                             int64_t* tdir) {
+  if (n == 0) return PP_OK;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t b_q = al256((size_t)n * 48), b_c = al256((size_t)n * PP_RS_MAX_PATHS * sizeof(PpRsCand));
+  const size_t b_p = al256((size_t)n * sizeof(PpRsPair)), b_4 = al256((size_t)n * 4), b_8 = al256((size_t)n * 8);
+  const size_t b_t = al256((size_t)n * cap * 8);
+  int32_t st = pp_scratch_reserve(ctx, b_q + b_c + b_p + 3 * b_4 + b_8 + 4 * b_t);
+  if (st != PP_OK) return st;
+  char* b = (char*)ctx->scratch;
+  double* d_q = (double*)b; b += b_q;
+  PpRsCand* d_c = (PpRsCand*)b; b += b_c;
+  PpRsPair* d_p = (PpRsPair*)b; b += b_p;
+  int32_t* d_sel = (int32_t*)b; b += b_4;
+  uint32_t* d_np = (uint32_t*)b; b += b_4;
+  uint32_t* d_fl = (uint32_t*)b; b += b_4;
+  double* d_tot = (double*)b; b += b_8;
+  double* d_tx = (double*)b; b += b_t;
+  double* d_ty = (double*)b; b += b_t;
+  double* d_tyaw = (double*)b; b += b_t;
+  int64_t* d_td = (int64_t*)b;
+  hipStream_t s = ctx->stream;
+  PP_HIP(ctx, hipMemcpyAsync(d_q, q6, (size_t)n * 48, hipMemcpyHostToDevice, s));
+  PP_HIP(ctx, hipMemcpyAsync(d_sel, sel, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  pp_rs_words_launch(ctx, n, d_q, maxc, d_c, d_p);
+  hipLaunchKernelGGL(k_rs_traj_sel, dim3(n), dim3(64), 0, s, n, d_q, d_q + n, d_q + 2 * (size_t)n, maxc,
+                     step_size, d_c, d_p, d_sel, cap, d_np, d_tot, d_fl, d_tx, d_ty, d_tyaw, d_td);
+  PP_HIP(ctx, hipGetLastError());
+  PP_HIP(ctx, hipMemcpyAsync(npts, d_np, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(flags, d_fl, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(total, d_tot, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(tx, d_tx, (size_t)n * cap * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(ty, d_ty, (size_t)n * cap * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(tyaw, d_tyaw, (size_t)n * cap * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(tdir, d_td, (size_t)n * cap * 8, hipMemcpyDeviceToHost, s));
   PP_HIP(ctx, hipStreamSynchronize(s));
   return PP_OK;
 }

@@ -78,18 +78,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks:
+    # ranks share the devices round-robin and the reductions travel through host memory.
+    backend = os.environ.get("PP_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
+    rdev = dev if backend == "nccl" else torch.device("cpu")  # where reduction tensors live
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     stream = torch.cuda.Stream(device=dev)
-    ctx = api.Context(local_rank, stream.cuda_stream)
+    ctx = api.Context(dev_index, stream.cuda_stream)
     conf = A.demo_config()
     if args.band > 0:
         assert ctx.lib.pp_ctx_set_relax_band(ctx.h, args.band) == 0
@@ -209,11 +217,11 @@ def main():
     elapsed = t1 - t0
     dev_ms = ev0.elapsed_time(ev1) / args.steps  # mean duration of one launch on its stream
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if world > 1:
-        tu = torch.tensor([units], dtype=torch.int64, device=dev)
+        tu = torch.tensor([units], dtype=torch.int64, device=rdev)
         dist.all_reduce(tu)
         total_units = int(tu.item()) * args.steps
     else:

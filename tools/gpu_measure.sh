@@ -26,15 +26,16 @@ step bench_rs 300 python3 -u bench.py --workload rs --steps 10
 tail -1 "$O/bench_rs.log"
 step bench_wave4096 300 python3 -u bench.py --workload wavefront --cells 4096 --steps 3 --warmup 1
 tail -1 "$O/bench_wave4096.log"
-if [ "${1:-}" = "full" ]; then
-  step bench_wave16384 600 python3 -u bench.py --workload wavefront --cells 16384 --steps 2 --warmup 1 --no-cpu-baseline
-  tail -1 "$O/bench_wave16384.log"
-fi
+step bench_wave16384 600 python3 -u bench.py --workload wavefront --cells 16384 --steps 3 --warmup 1 --no-cpu-baseline
+tail -1 "$O/bench_wave16384.log"
+step bench_queries 600 python3 -u bench.py --workload queries --steps 3 --warmup 1
+tail -1 "$O/bench_queries.log"
 export TMPDIR=/tmp
 cd /tmp || exit 1
 step prof_collision 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_collision" -- python3 "$R/bench.py" --no-cpu-baseline
 step prof_rs 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_rs" -- python3 "$R/bench.py" --workload rs --steps 10 --no-cpu-baseline
-step prof_wave 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_wave" -- python3 "$R/bench.py" --workload wavefront --cells 4096 --steps 3 --warmup 1 --no-cpu-baseline
+step prof_wave 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_wave" -- python3 "$R/bench.py" --workload wavefront --cells 16384 --steps 2 --warmup 1 --no-cpu-baseline
+step prof_queries 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_queries" -- python3 "$R/bench.py" --workload queries --steps 2 --warmup 1 --no-cpu-baseline
 # HBM traffic: separate counter passes, no tracing domains
 step pmc_fetchsize 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/bench.py" --no-cpu-baseline --steps 3 --warmup 1
 step pmc_writesize 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 "$R/bench.py" --no-cpu-baseline --steps 3 --warmup 1

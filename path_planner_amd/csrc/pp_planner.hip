@@ -9,6 +9,8 @@
 // of work per step, so queries are advanced in lock-step rounds: every live query closes one
 // node, one launch set expands all of them, and the host applies the results to each query's
 // heap (over a small thread pool, queries being independent).
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -183,6 +185,7 @@ double now_ms() {
 extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, uint64_t nq,
                                  const double* starts, const double* goals, pp_path* out,
                                  pp_plan_stats* stats, int32_t* status) {
+  const double t_entry = now_ms();
   if (!ctx || !map || !conf || (nq && (!starts || !goals || !out))) return PP_ERR_INVALID;
   if (map->ox.empty()) return PP_ERR_EMPTY_MAP;
   if (!map->finite) return PP_ERR_NONFINITE;
@@ -332,37 +335,25 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     off += al256(bytes);
     return o;
   };
-  // inputs: q[6][B] (start pose + goal pose), pdir, psteer, pcost, hmap_id, motion
-  const size_t o_q = take(6 * B * 8), o_dir = take(B * 8), o_steer = take(B * 8), o_cost = take(B * 8);
-  const size_t o_hid = take(B * 4), o_mot = take(plan.motion.size() * 8);
-  const size_t in_bytes = off;
-  // outputs
-  const size_t o_shot = take(B * sizeof(PpShotOut));
-  const size_t o_valid = take(items), o_xind = take(items * 8), o_yind = take(items * 8), o_yaw = take(items * 8);
-  const size_t o_c = take(items * 8), o_ex = take(items * 8), o_ey = take(items * 8), o_eyaw = take(items * 8);
-  const size_t o_f = take(items * 8);
-  const size_t out_bytes = off - in_bytes;
+  // per-round inputs (start pose + goal pose, pdir, psteer, pcost, hmap_id) and outputs share one
+  // device buffer and one pinned mirror, laid out per round; the motion table and the
+  // Reeds-Shepp work arrays sit behind them
+  const size_t io_bytes = al256(6 * B * 8) + 3 * al256(B * 8) + al256(B * 4) + al256(B * sizeof(PpShotOut)) +
+                          al256(items) + 8 * al256(items * 8);
+  off = io_bytes;
+  const size_t o_mot = take(plan.motion.size() * 8);
   const size_t o_cand = take(B * PP_RS_MAX_PATHS * sizeof(PpRsCand)), o_pair = take(B * sizeof(PpRsPair));
   DevBuf dev;
   PinBuf pin;
   PP_HIP(ctx, hipMalloc(&dev.p, off));
-  PP_HIP(ctx, hipHostMalloc(&pin.p, in_bytes + out_bytes, hipHostMallocDefault));
+  PP_HIP(ctx, hipHostMalloc(&pin.p, io_bytes, hipHostMallocDefault));
   char* d = (char*)dev.p;
   char* h = (char*)pin.p;
-  std::memcpy(h + o_mot, plan.motion.data(), plan.motion.size() * 8);
+  const double* d_mot = (const double*)(d + o_mot);
+  PP_HIP(ctx, hipMemcpyAsync(d + o_mot, plan.motion.data(), plan.motion.size() * 8, hipMemcpyHostToDevice, s));
 
-  PpExpandDev eo;
-  eo.valid = (uint8_t*)(d + o_valid);
-  eo.xind = (uint64_t*)(d + o_xind);
-  eo.yind = (uint64_t*)(d + o_yind);
-  eo.yawind = (int64_t*)(d + o_yaw);
-  eo.cost = (double*)(d + o_c);
-  eo.end_x = (double*)(d + o_ex);
-  eo.end_y = (double*)(d + o_ey);
-  eo.end_yaw = (double*)(d + o_eyaw);
-  eo.fcost = (double*)(d + o_f);
+  PpExpandDev eo{};
   eo.hmaps = (const double* const*)tab_buf.p;
-  eo.hmap_id = (const int32_t*)(d + o_hid);
   eo.hxw = hxw;
   eo.hyw = hyw;
   eo.h_cost = conf->h_cost;
@@ -412,12 +403,27 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     const size_t nl = live_ids.size();
     if (nl == 0) break;
 
-    // (2) stage parents, launch, fetch
-    double* hq = (double*)(h + o_q);
-    int64_t* hdir = (int64_t*)(h + o_dir);
-    double* hsteer = (double*)(h + o_steer);
-    double* hcost = (double*)(h + o_cost);
-    int32_t* hhid = (int32_t*)(h + o_hid);
+    // (2) stage parents, launch, fetch.  Inputs and outputs are laid out for this round's
+    // number of live queries, so each direction is one copy of exactly what is used.
+    size_t ro = 0;
+    auto rtake = [&](size_t bytes) {
+      size_t o = ro;
+      ro += al256(bytes);
+      return o;
+    };
+    const size_t r_q = rtake(6 * nl * 8), r_dir = rtake(nl * 8), r_steer = rtake(nl * 8), r_cost = rtake(nl * 8);
+    const size_t r_hid = rtake(nl * 4);
+    const size_t r_in = ro;
+    const size_t itn = nl * NP;
+    const size_t r_shot = rtake(nl * sizeof(PpShotOut)), r_valid = rtake(itn);
+    const size_t r_xind = rtake(itn * 8), r_yind = rtake(itn * 8), r_yaw = rtake(itn * 8), r_c = rtake(itn * 8);
+    const size_t r_ex = rtake(itn * 8), r_ey = rtake(itn * 8), r_eyaw = rtake(itn * 8), r_f = rtake(itn * 8);
+    const size_t r_out = ro - r_in;
+    double* hq = (double*)(h + r_q);
+    int64_t* hdir = (int64_t*)(h + r_dir);
+    double* hsteer = (double*)(h + r_steer);
+    double* hcost = (double*)(h + r_cost);
+    int32_t* hhid = (int32_t*)(h + r_hid);
     for (size_t k = 0; k < nl; ++k) {
       const Query& q = Q[live_ids[k]];
       const SNode& n = q.nodes[q.curr];
@@ -432,35 +438,38 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       hcost[k] = n.cost;
       hhid[k] = q.hmap_slot;
     }
-    PP_HIP(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
-    const double* dq = (const double*)(d + o_q);
+    PP_HIP(ctx, hipMemcpyAsync(d, h, r_in, hipMemcpyHostToDevice, s));
+    eo.valid = (uint8_t*)(d + r_valid);
+    eo.xind = (uint64_t*)(d + r_xind);
+    eo.yind = (uint64_t*)(d + r_yind);
+    eo.yawind = (int64_t*)(d + r_yaw);
+    eo.cost = (double*)(d + r_c);
+    eo.end_x = (double*)(d + r_ex);
+    eo.end_y = (double*)(d + r_ey);
+    eo.end_yaw = (double*)(d + r_eyaw);
+    eo.fcost = (double*)(d + r_f);
+    eo.hmap_id = (const int32_t*)(d + r_hid);
+    const double* dq = (const double*)(d + r_q);
     pp_rs_words_launch(ctx, nl, dq, maxc, (PpRsCand*)(d + o_cand), (PpRsPair*)(d + o_pair));
     pp_rs_shot_launch(ctx, map, conf, (uint32_t)nl, dq, maxc, (const PpRsCand*)(d + o_cand),
-                      (const PpRsPair*)(d + o_pair), (PpShotOut*)(d + o_shot));
-    pp_expand_launch(ctx, map, plan, nl, dq, dq + nl, dq + 2 * nl, (const int64_t*)(d + o_dir),
-                     (const double*)(d + o_steer), (const double*)(d + o_cost),
-                     (const double*)(d + o_mot), eo);
+                      (const PpRsPair*)(d + o_pair), (PpShotOut*)(d + r_shot));
+    pp_expand_launch(ctx, map, plan, nl, dq, dq + nl, dq + 2 * nl, (const int64_t*)(d + r_dir),
+                     (const double*)(d + r_steer), (const double*)(d + r_cost), (const double*)d_mot, eo);
     PP_HIP(ctx, hipGetLastError());
-    {  // fetch only what this round produced
-      const size_t it8 = nl * NP * 8;
-      PP_HIP(ctx, hipMemcpyAsync(h + o_shot, d + o_shot, nl * sizeof(PpShotOut), hipMemcpyDeviceToHost, s));
-      PP_HIP(ctx, hipMemcpyAsync(h + o_valid, d + o_valid, nl * NP, hipMemcpyDeviceToHost, s));
-      const size_t offs[8] = {o_xind, o_yind, o_yaw, o_c, o_ex, o_ey, o_eyaw, o_f};
-      for (size_t o : offs) PP_HIP(ctx, hipMemcpyAsync(h + o, d + o, it8, hipMemcpyDeviceToHost, s));
-    }
+    PP_HIP(ctx, hipMemcpyAsync(h + r_in, d + r_in, r_out, hipMemcpyDeviceToHost, s));
     PP_HIP(ctx, hipStreamSynchronize(s));
 
     // (3) apply (hybrid_astar.rs:176-209)
-    const PpShotOut* shot = (const PpShotOut*)(h + o_shot);
-    const uint8_t* v_valid = (const uint8_t*)(h + o_valid);
-    const uint64_t* v_x = (const uint64_t*)(h + o_xind);
-    const uint64_t* v_y = (const uint64_t*)(h + o_yind);
-    const int64_t* v_yaw = (const int64_t*)(h + o_yaw);
-    const double* v_c = (const double*)(h + o_c);
-    const double* v_ex = (const double*)(h + o_ex);
-    const double* v_ey = (const double*)(h + o_ey);
-    const double* v_eyaw = (const double*)(h + o_eyaw);
-    const double* v_f = (const double*)(h + o_f);
+    const PpShotOut* shot = (const PpShotOut*)(h + r_shot);
+    const uint8_t* v_valid = (const uint8_t*)(h + r_valid);
+    const uint64_t* v_x = (const uint64_t*)(h + r_xind);
+    const uint64_t* v_y = (const uint64_t*)(h + r_yind);
+    const int64_t* v_yaw = (const int64_t*)(h + r_yaw);
+    const double* v_c = (const double*)(h + r_c);
+    const double* v_ex = (const double*)(h + r_ex);
+    const double* v_ey = (const double*)(h + r_ey);
+    const double* v_eyaw = (const double*)(h + r_eyaw);
+    const double* v_f = (const double*)(h + r_f);
     const double* mot = plan.motion.data();
     pool.run(nl, [&](size_t k) {
       Query& q = Q[live_ids[k]];
@@ -585,67 +594,37 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     st = pp_rollout_points_batch(ctx, conf, nroll_all, in5.data(), lx.data(), ly.data(), lyaw.data(), &nlist);
     if (st != PP_OK) return st;
   }
-  // analytic-shot trajectories; windows that turn out too small are redone with the size needed
-  uint32_t cap_rs = 1024;
-  std::vector<double> rx, ry, ryaw, rtotal(nf);
+  // analytic-shot trajectories of all found queries, packed
+  std::vector<double> rx, ry, ryaw, rtotal;
   std::vector<int64_t> rdir;
-  std::vector<uint32_t> rnp(nf), rfl(nf);
-  std::vector<uint32_t> rcap(nf, 0);       // window size each query's trajectory was written with
-  std::vector<size_t> rbase(nf, 0);
+  std::vector<uint32_t> rfl;
+  std::vector<uint64_t> roff;
   {
-    std::vector<uint32_t> todo(nf);
-    for (uint32_t k = 0; k < nf; ++k) todo[k] = k;
-    while (!todo.empty()) {
-      const uint32_t n = (uint32_t)todo.size();
-      std::vector<double> q6((size_t)6 * n);
-      std::vector<int32_t> sel(n);
-      for (uint32_t k = 0; k < n; ++k) {
-        const Query& q = Q[found[todo[k]].q];
-        const SNode& fp = q.nodes[q.final_parent];
-        q6[k] = fp.x;
-        q6[n + k] = fp.y;
-        q6[2 * (size_t)n + k] = fp.yaw;
-        q6[3 * (size_t)n + k] = q.goal[0];
-        q6[4 * (size_t)n + k] = q.goal[1];
-        q6[5 * (size_t)n + k] = q.goal[2];
-        sel[k] = q.final_rs_idx;
-      }
-      const size_t base = rx.size();
-      rx.resize(base + (size_t)n * cap_rs);
-      ry.resize(rx.size());
-      ryaw.resize(rx.size());
-      rdir.resize(rx.size());
-      std::vector<uint32_t> np(n), fl(n);
-      std::vector<double> tot(n);
-      st = pp_rs_selected_batch(ctx, n, q6.data(), maxc, conf->move_step, sel.data(), cap_rs, np.data(),
-                                tot.data(), fl.data(), rx.data() + base, ry.data() + base,
-                                ryaw.data() + base, rdir.data() + base);
-      if (st != PP_OK) return st;
-      std::vector<uint32_t> again;
-      uint32_t need = 0;
-      for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t id = todo[k];
-        rnp[id] = np[k];
-        rfl[id] = fl[k];
-        rtotal[id] = tot[k];
-        rcap[id] = cap_rs;
-        rbase[id] = base + (size_t)k * cap_rs;
-        if (np[k] > cap_rs) {
-          again.push_back(id);
-          need = std::max(need, np[k]);
-        }
-      }
-      todo.swap(again);
-      cap_rs = need;
+    std::vector<double> q6((size_t)6 * nf);
+    std::vector<int32_t> sel(nf);
+    for (uint32_t k = 0; k < nf; ++k) {
+      const Query& q = Q[found[k].q];
+      const SNode& fp = q.nodes[q.final_parent];
+      q6[k] = fp.x;
+      q6[nf + k] = fp.y;
+      q6[2 * (size_t)nf + k] = fp.yaw;
+      q6[3 * (size_t)nf + k] = q.goal[0];
+      q6[4 * (size_t)nf + k] = q.goal[1];
+      q6[5 * (size_t)nf + k] = q.goal[2];
+      sel[k] = q.final_rs_idx;
     }
+    st = pp_rs_selected_batch(ctx, nf, q6.data(), maxc, conf->move_step, sel.data(), roff, rtotal, rfl, rx,
+                              ry, ryaw, rdir);
+    if (st != PP_OK) return st;
   }
-  for (uint32_t k = 0; k < nf; ++k) {
+  pool.run(nf, [&](size_t k) {
     const Found& f = found[k];
     Query& q = Q[f.q];
     pp_path& po = out[f.q];
-    if ((rfl[k] & (4u | 8u | 16u)) || rnp[k] == 0) {
+    const uint64_t rnp_k = roff[k + 1] - roff[k];
+    if ((rfl[k] & (4u | 8u | 16u)) || rnp_k == 0) {
       q.status = PP_ERR_DEGENERATE_RS;
-      continue;
+      return;
     }
     q.st.rs_final_length = rtotal[k];
     const SNode& fp = q.nodes[q.final_parent];
@@ -654,8 +633,8 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     std::vector<int64_t> D;
     double cost = 0.0;
     if (f.with_final) {
-      const size_t a = rbase[k];
-      for (uint64_t j = rnp[k]; j-- > 1;) {  // node.x[1..].rev() of the RS node
+      const size_t a = roff[k];
+      for (uint64_t j = rnp_k; j-- > 1;) {  // node.x[1..].rev() of the RS node
         X.push_back(rx[a + j]);
         Y.push_back(ry[a + j]);
         YAW.push_back(ryaw[a + j]);
@@ -694,9 +673,10 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       }
       q.status = PP_OK;
     }
-  }
+  });
   const double t_extract = now_ms();
-  (void)t_extract;
+  if (getenv("PP_PLAN_PROFILE"))
+    fprintf(stderr, "[plan] entry->begin %.1f heur %.1f search(incl. staging alloc) %.1f extract %.1f ms\n", t_begin - t_entry, t_heur - t_begin, t_search - t_heur, t_extract - t_search);
   for (uint64_t i = 0; i < nq; ++i) {
     Query& q = Q[i];
     q.st.t_heuristic_ms = t_heur - t_begin;

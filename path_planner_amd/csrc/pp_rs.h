@@ -2,6 +2,8 @@
 #ifndef PP_RS_H_
 #define PP_RS_H_
 
+#include <vector>
+
 #include "pp_internal.h"
 
 // One accepted word, lengths in normalised (curvature) units, stored at its generation index.
@@ -43,10 +45,11 @@ int32_t pp_rs_single(pp_ctx* ctx, const double q[6], double maxc, double step_si
                      int32_t* n_paths, pp_rs_word* words, uint64_t* traj_off, double* traj_x,
                      double* traj_y, double* traj_yaw, int64_t* traj_dir, uint64_t traj_cap,
                      uint32_t* flags_out);
-// Trajectory of the path with rank sel[i] of each of n pairs (host arrays; q6 = six arrays of n),
-// `cap` points per pair; npts[i] > cap means the window was too small and nothing was written.
+// Trajectory of the path with rank sel[i] of each of n pairs (q6 = six host arrays of n), tightly
+// packed: pair i's points are [offs[i], offs[i + 1]) of the output vectors.
 int32_t pp_rs_selected_batch(pp_ctx* ctx, uint32_t n, const double* q6, double maxc, double step_size,
-                             const int32_t* sel, uint32_t cap, uint32_t* npts, double* total,
-                             uint32_t* flags, double* tx, double* ty, double* tyaw, int64_t* tdir);
+                             const int32_t* sel, std::vector<uint64_t>& offs, std::vector<double>& total,
+                             std::vector<uint32_t>& flags, std::vector<double>& tx, std::vector<double>& ty,
+                             std::vector<double>& tyaw, std::vector<int64_t>& tdir);
 
 #endif

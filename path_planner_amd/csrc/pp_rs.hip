@@ -5,6 +5,8 @@
 #include <algorithm>
 
 #include "pp_device.h"
+#include <vector>
+
 #include "pp_rs.h"
 #include "pp_rs_device.h"
 
@@ -100,21 +102,52 @@ struct AllSink {
   }
 };
 
-__global__ void __launch_bounds__(128)
+// Words of n pairs, every accepted candidate kept.  A block takes 64 pairs; its seven waves each
+// evaluate one candidate family for all of them (the families' duplicate tests are independent),
+// so a small batch -- one analytic shot per planner round -- waits for the longest family, not
+// for all 46 candidates in a row.
+__global__ void __launch_bounds__(64 * kRsFamilies)
 k_rs_words(uint64_t n, const double* __restrict__ sx, const double* __restrict__ sy,
            const double* __restrict__ syaw, const double* __restrict__ gx,
            const double* __restrict__ gy, const double* __restrict__ gyaw, double maxc,
            PpRsCand* __restrict__ cands, PpRsPair* __restrict__ pairs) {
-  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  __shared__ unsigned long long acc[kRsFamilies][64];
+  __shared__ uint32_t fl[kRsFamilies][64];
+  const uint32_t lane = threadIdx.x & 63u, fam = threadIdx.x >> 6;
+  for (uint64_t b0 = (uint64_t)blockIdx.x * 64; b0 < n; b0 += (uint64_t)gridDim.x * 64) {
+    const uint64_t i = b0 + lane;
     PpRsState S;
-    AllSink sink{cands + i * PP_RS_MAX_PATHS};
-    pp_rs_generate(sx[i], sy[i], syaw[i], gx[i], gy[i], gyaw[i], maxc, S, sink);
-    PpRsPair p;
-    p.accepted = S.degenerate ? 0ull : S.accepted;
-    p.flags = (S.degenerate ? 4u : 0u) | (S.A.amb ? 2u : 0u);
-    p.n_paths = __popcll(p.accepted);
-    pairs[i] = p;
+    if (i < n) {
+      const PpRsInput in = pp_rs_input(sx[i], sy[i], syaw[i], gx[i], gy[i], gyaw[i], maxc);
+      AllSink sink{cands + i * PP_RS_MAX_PATHS};
+      switch (fam) {  // wave-uniform
+        case 0: pp_rs_family<0>(in, S, sink); break;
+        case 1: pp_rs_family<1>(in, S, sink); break;
+        case 2: pp_rs_family<2>(in, S, sink); break;
+        case 3: pp_rs_family<3>(in, S, sink); break;
+        case 4: pp_rs_family<4>(in, S, sink); break;
+        case 5: pp_rs_family<5>(in, S, sink); break;
+        default: pp_rs_family<6>(in, S, sink); break;
+      }
+    }
+    acc[fam][lane] = S.accepted;
+    fl[fam][lane] = (S.degenerate ? 4u : 0u) | (S.A.amb ? 2u : 0u);
+    __syncthreads();
+    if (fam == 0 && i < n) {
+      unsigned long long a = 0;
+      uint32_t f = 0;
+#pragma unroll
+      for (int k = 0; k < kRsFamilies; ++k) {
+        a |= acc[k][lane];
+        f |= fl[k][lane];
+      }
+      PpRsPair p;
+      p.accepted = (f & 4u) ? 0ull : a;
+      p.flags = f;
+      p.n_paths = __popcll(p.accepted);
+      pairs[i] = p;
+    }
+    __syncthreads();
   }
 }
 
@@ -443,14 +476,16 @@ k_rs_traj(double x0, double y0, double yaw0, double maxc, double step_size,
 // ------------------------------------------------------------------ one chosen path per pair
 
 // Trajectory of the path with rank sel[pair] (generation order among the accepted words) of each
-// pair, into a fixed window of `cap` points per pair.  One wave per pair.
+// pair.  One wave per pair.  With offs == nullptr only the point counts are produced; otherwise
+// pair p's points go to [offs[p], offs[p + 1]) of the trajectory arrays.
 __global__ void __launch_bounds__(64)
 k_rs_traj_sel(uint32_t n, const double* __restrict__ sx, const double* __restrict__ sy,
               const double* __restrict__ syaw, double maxc, double step_size,
               const PpRsCand* __restrict__ cands, const PpRsPair* __restrict__ pairs,
-              const int32_t* __restrict__ sel, uint32_t cap, uint32_t* __restrict__ npts,
-              double* __restrict__ total, uint32_t* __restrict__ flags, double* __restrict__ tx,
-              double* __restrict__ ty, double* __restrict__ tyaw, int64_t* __restrict__ tdir) {
+              const int32_t* __restrict__ sel, const uint64_t* __restrict__ offs,
+              uint32_t* __restrict__ npts, double* __restrict__ total, uint32_t* __restrict__ flags,
+              double* __restrict__ tx, double* __restrict__ ty, double* __restrict__ tyaw,
+              int64_t* __restrict__ tdir) {
   __shared__ PathPlan plan;
   __shared__ int ok;
   const uint32_t pair = blockIdx.x;
@@ -461,35 +496,40 @@ k_rs_traj_sel(uint32_t n, const double* __restrict__ sx, const double* __restric
     const int rank = sel[pair];
     uint32_t fl = pr.flags;
     ok = 0;
-    npts[pair] = 0;
-    total[pair] = 0.0;
+    uint32_t np = 0;
+    double tot = 0.0;
     if (rank >= 0 && rank < pr.n_paths) {
       uint64_t m = pr.accepted;
       for (int k = 0; k < rank; ++k) m &= m - 1;
       const PpRsCand c = cands[(size_t)pair * PP_RS_MAX_PATHS + __builtin_ctzll(m)];
       plan_path(c, maxc, step_size * maxc, plan);
       trim_path(plan, maxc);
-      npts[pair] = (uint32_t)plan.npts;
-      total[pair] = c.total / maxc;  // reeds_shepp.rs:125
+      np = (uint32_t)plan.npts;
+      tot = c.total / maxc;  // reeds_shepp.rs:125
       if (plan.amb) fl |= 2u;
       if (plan.npts == 0) fl |= 8u;  // px.last().unwrap() on an emptied Vec panics
-      ok = plan.npts > 0 && (uint32_t)plan.npts <= cap;
+      ok = offs != nullptr && plan.npts > 0 && (uint64_t)plan.npts == offs[pair + 1] - offs[pair];
     } else {
       fl |= 16u;
     }
-    flags[pair] = fl;
+    if (!offs) {
+      npts[pair] = np;
+      total[pair] = tot;
+      flags[pair] = fl;
+    }
   }
   __syncthreads();
   if (!ok) return;
   const double x0 = sx[pair], y0 = sy[pair], yaw0 = syaw[pair];
   double s0, c0;
   sincos(yaw0, &s0, &c0);
+  const uint64_t base = offs[pair];
   for (int j = lane; j < plan.npts; j += 64) {
     double lx, ly, lyaw, X, Y, YAW;
     int dir;
     local_point(plan, j, maxc, lx, ly, lyaw, dir);
     to_global(lx, ly, lyaw, x0, y0, yaw0, c0, s0, X, Y, YAW);
-    const size_t o = (size_t)pair * cap + (size_t)j;
+    const uint64_t o = base + (uint64_t)j;
     tx[o] = X;
     ty[o] = Y;
     tyaw[o] = YAW;
@@ -515,8 +555,8 @@ PpCostParams cost_params(const pp_config* conf) {
 
 void pp_rs_words_launch(pp_ctx* ctx, uint64_t n, const double* d_q /* 6 arrays of n */, double maxc,
                         PpRsCand* d_cands, PpRsPair* d_pairs) {
-  unsigned grid = pp_stream_grid(ctx, n, 128);
-  hipLaunchKernelGGL(k_rs_words, dim3(grid), dim3(128), 0, ctx->stream, n, d_q, d_q + n, d_q + 2 * n,
+  unsigned grid = pp_stream_grid(ctx, n, 64);
+  hipLaunchKernelGGL(k_rs_words, dim3(grid), dim3(64 * kRsFamilies), 0, ctx->stream, n, d_q, d_q + n, d_q + 2 * n,
                      d_q + 3 * n, d_q + 4 * n, d_q + 5 * n, maxc, d_cands, d_pairs);
 }
 
@@ -581,45 +621,83 @@ extern "C" int32_t pp_rs_batch(pp_ctx* ctx, uint64_t n, const double* sx, const 
   return PP_OK;
 }
 
-// The chosen path (rank sel[i]) of n pairs with its trajectory: host in, host out, `cap` points per
-// pair.  flags: the pair's word flags, | 8 trajectory emptied by the trim, | 16 rank out of range.
+// The chosen path (rank sel[i]) of n pairs with its trajectory, tightly packed: pair i's points
+// are [offs[i], offs[i + 1]) of the output vectors.  flags: the pair's word flags, | 8 trajectory
+// emptied by the trim, | 16 rank out of range.
 int32_t pp_rs_selected_batch(pp_ctx* ctx, uint32_t n, const double* q6 /* 6 arrays of n */, double maxc,
-                             double step_size, const int32_t* sel, uint32_t cap, uint32_t* npts,
-                             double* total, uint32_t* flags, double* tx, double* ty, double* tyaw,
-                             int64_t* tdir) {
+                             double step_size, const int32_t* sel, std::vector<uint64_t>& offs,
+                             std::vector<double>& total, std::vector<uint32_t>& flags,
+                             std::vector<double>& tx, std::vector<double>& ty, std::vector<double>& tyaw,
+                             std::vector<int64_t>& tdir) {
+  offs.assign((size_t)n + 1, 0);
+  total.assign(n, 0.0);
+  flags.assign(n, 0);
   if (n == 0) return PP_OK;
   PP_HIP(ctx, hipSetDevice(ctx->device));
-  const size_t b_q = al256((size_t)n * 48), b_c = al256((size_t)n * PP_RS_MAX_PATHS * sizeof(PpRsCand));
-  const size_t b_p = al256((size_t)n * sizeof(PpRsPair)), b_4 = al256((size_t)n * 4), b_8 = al256((size_t)n * 8);
-  const size_t b_t = al256((size_t)n * cap * 8);
-  int32_t st = pp_scratch_reserve(ctx, b_q + b_c + b_p + 3 * b_4 + b_8 + 4 * b_t);
-  if (st != PP_OK) return st;
-  char* b = (char*)ctx->scratch;
-  double* d_q = (double*)b; b += b_q;
-  PpRsCand* d_c = (PpRsCand*)b; b += b_c;
-  PpRsPair* d_p = (PpRsPair*)b; b += b_p;
-  int32_t* d_sel = (int32_t*)b; b += b_4;
-  uint32_t* d_np = (uint32_t*)b; b += b_4;
-  uint32_t* d_fl = (uint32_t*)b; b += b_4;
-  double* d_tot = (double*)b; b += b_8;
-  double* d_tx = (double*)b; b += b_t;
-  double* d_ty = (double*)b; b += b_t;
-  double* d_tyaw = (double*)b; b += b_t;
-  int64_t* d_td = (int64_t*)b;
   hipStream_t s = ctx->stream;
+  const size_t b_q = al256((size_t)n * 48), b_c = al256((size_t)n * PP_RS_MAX_PATHS * sizeof(PpRsCand));
+  const size_t b_p = al256((size_t)n * sizeof(PpRsPair)), b_4 = al256((size_t)n * 4), b_8 = al256((size_t)n * 8 + 8);
+  const size_t fixed = b_q + b_c + b_p + 3 * b_4 + 2 * b_8;
+  int32_t st = pp_scratch_reserve(ctx, fixed);
+  if (st != PP_OK) return st;
+  auto carve = [&](char* b, double*& d_q, PpRsCand*& d_c, PpRsPair*& d_p, int32_t*& d_sel, uint32_t*& d_np,
+                   uint32_t*& d_fl, double*& d_tot, uint64_t*& d_off) {
+    d_q = (double*)b; b += b_q;
+    d_c = (PpRsCand*)b; b += b_c;
+    d_p = (PpRsPair*)b; b += b_p;
+    d_sel = (int32_t*)b; b += b_4;
+    d_np = (uint32_t*)b; b += b_4;
+    d_fl = (uint32_t*)b; b += b_4;
+    d_tot = (double*)b; b += b_8;
+    d_off = (uint64_t*)b;
+  };
+  double* d_q; PpRsCand* d_c; PpRsPair* d_p; int32_t* d_sel; uint32_t *d_np, *d_fl; double* d_tot; uint64_t* d_off;
+  carve((char*)ctx->scratch, d_q, d_c, d_p, d_sel, d_np, d_fl, d_tot, d_off);
   PP_HIP(ctx, hipMemcpyAsync(d_q, q6, (size_t)n * 48, hipMemcpyHostToDevice, s));
   PP_HIP(ctx, hipMemcpyAsync(d_sel, sel, (size_t)n * 4, hipMemcpyHostToDevice, s));
   pp_rs_words_launch(ctx, n, d_q, maxc, d_c, d_p);
+  // pass 1: point counts
   hipLaunchKernelGGL(k_rs_traj_sel, dim3(n), dim3(64), 0, s, n, d_q, d_q + n, d_q + 2 * (size_t)n, maxc,
-                     step_size, d_c, d_p, d_sel, cap, d_np, d_tot, d_fl, d_tx, d_ty, d_tyaw, d_td);
+                     step_size, d_c, d_p, d_sel, (const uint64_t*)nullptr, d_np, d_tot, d_fl,
+                     (double*)nullptr, (double*)nullptr, (double*)nullptr, (int64_t*)nullptr);
   PP_HIP(ctx, hipGetLastError());
-  PP_HIP(ctx, hipMemcpyAsync(npts, d_np, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-  PP_HIP(ctx, hipMemcpyAsync(flags, d_fl, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-  PP_HIP(ctx, hipMemcpyAsync(total, d_tot, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-  PP_HIP(ctx, hipMemcpyAsync(tx, d_tx, (size_t)n * cap * 8, hipMemcpyDeviceToHost, s));
-  PP_HIP(ctx, hipMemcpyAsync(ty, d_ty, (size_t)n * cap * 8, hipMemcpyDeviceToHost, s));
-  PP_HIP(ctx, hipMemcpyAsync(tyaw, d_tyaw, (size_t)n * cap * 8, hipMemcpyDeviceToHost, s));
-  PP_HIP(ctx, hipMemcpyAsync(tdir, d_td, (size_t)n * cap * 8, hipMemcpyDeviceToHost, s));
+  std::vector<uint32_t> np(n);
+  PP_HIP(ctx, hipMemcpyAsync(np.data(), d_np, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(flags.data(), d_fl, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(total.data(), d_tot, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipStreamSynchronize(s));
+  for (uint32_t i = 0; i < n; ++i) offs[i + 1] = offs[i] + np[i];
+  const uint64_t tot_pts = offs[n];
+  tx.resize(tot_pts);
+  ty.resize(tot_pts);
+  tyaw.resize(tot_pts);
+  tdir.resize(tot_pts);
+  if (tot_pts == 0) return PP_OK;
+  // pass 2: the points, packed.  The words are generated again if the scratch buffer has to move.
+  const size_t b_t = al256(tot_pts * 8);
+  const void* before = ctx->scratch;
+  st = pp_scratch_reserve(ctx, fixed + 4 * b_t);
+  if (st != PP_OK) return st;
+  if (ctx->scratch != before) {
+    carve((char*)ctx->scratch, d_q, d_c, d_p, d_sel, d_np, d_fl, d_tot, d_off);
+    PP_HIP(ctx, hipMemcpyAsync(d_q, q6, (size_t)n * 48, hipMemcpyHostToDevice, s));
+    PP_HIP(ctx, hipMemcpyAsync(d_sel, sel, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    pp_rs_words_launch(ctx, n, d_q, maxc, d_c, d_p);
+  }
+  char* tb = (char*)ctx->scratch + fixed;
+  double* d_tx = (double*)tb;
+  double* d_ty = (double*)(tb + b_t);
+  double* d_tyaw = (double*)(tb + 2 * b_t);
+  int64_t* d_td = (int64_t*)(tb + 3 * b_t);
+  PP_HIP(ctx, hipMemcpyAsync(d_off, offs.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_rs_traj_sel, dim3(n), dim3(64), 0, s, n, d_q, d_q + n, d_q + 2 * (size_t)n, maxc,
+                     step_size, d_c, d_p, d_sel, (const uint64_t*)d_off, d_np, d_tot, d_fl, d_tx, d_ty, d_tyaw,
+                     d_td);
+  PP_HIP(ctx, hipGetLastError());
+  PP_HIP(ctx, hipMemcpyAsync(tx.data(), d_tx, tot_pts * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(ty.data(), d_ty, tot_pts * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(tyaw.data(), d_tyaw, tot_pts * 8, hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(tdir.data(), d_td, tot_pts * 8, hipMemcpyDeviceToHost, s));
   PP_HIP(ctx, hipStreamSynchronize(s));
   return PP_OK;
 }

@@ -320,10 +320,9 @@ __device__ __forceinline__ void pp_pair(PpRsState& S, const PpRsInput& in, PpWor
   pp_candidate<F, K0 + 1, BACK, LAY, N>(S, in, ws, gen0 + K0 + 1, word_k0, sink);
 }
 
-// generate_path, :707-725.
-template <class Sink>
-__device__ __forceinline__ void pp_rs_generate(double sx, double sy, double syaw, double gx, double gy,
-                                               double gyaw, double maxc, PpRsState& S, Sink& sink) {
+// The start-frame, curvature-normalised goal (generate_path, :707-720).
+__device__ __forceinline__ PpRsInput pp_rs_input(double sx, double sy, double syaw, double gx, double gy,
+                                                 double gyaw, double maxc) {
   const double dx = gx - sx, dy = gy - sy, dth = gyaw - syaw;
   double s0, c0;
   sincos(syaw, &s0, &c0);
@@ -334,52 +333,75 @@ __device__ __forceinline__ void pp_rs_generate(double sx, double sy, double syaw
   sincos(dth, &in.sp, &in.cp);
   in.xb = in.x * in.cp + in.y * in.sp;  // :294-295, :482-483
   in.yb = in.x * in.sp - in.y * in.cp;
+  return in;
+}
 
-  {  // scs :202-211 -- generation indices 0, 1
+// The 46 candidates fall into seven groups whose duplicate tests (set_path compares only paths
+// with identical letters) never look outside the group, so the groups can be evaluated in any
+// order, or by different waves, and still accept exactly the reference's paths.
+constexpr int kRsFamilies = 7;
+
+template <int FAM, class Sink>
+__device__ __forceinline__ void pp_rs_family(const PpRsInput& in, PpRsState& S, Sink& sink) {
+  if constexpr (FAM == 0) {  // scs :202-211 -- generation indices 0, 1
     PpWordSet<3> a, b;
     pp_candidate<PP_F_SLS_, 0, false, PP_TUV, 3>(S, in, a, 0, pp_word("SLS"), sink);
     pp_candidate<PP_F_SLS_, 2, false, PP_TUV, 3>(S, in, b, 1, pp_word("SLS"), sink);
   }
-  {  // csc :231-270 -- 2..9
+  if constexpr (FAM == 1) {  // csc :231-270 -- 2..9
     PpWordSet<3> a, b, c, d;
     pp_pair<PP_F_LSL_, 0, false, PP_TUV, 3>(S, in, a, 2, pp_word("LSL"), sink);
     pp_pair<PP_F_LSL_, 2, false, PP_TUV, 3>(S, in, b, 2, pp_word("LSL"), sink);
     pp_pair<PP_F_LSR_, 0, false, PP_TUV, 3>(S, in, c, 6, pp_word("LSR"), sink);
     pp_pair<PP_F_LSR_, 2, false, PP_TUV, 3>(S, in, d, 6, pp_word("LSR"), sink);
   }
-  {  // ccc :272-316 -- 10..17; LRL / RLR each collect four candidates
+  if constexpr (FAM == 2) {  // ccc :272-316 -- 10..17; LRL / RLR each collect four candidates
     PpWordSet<3> a, b;
     pp_pair<PP_F_LRL_, 0, false, PP_TUV, 3>(S, in, a, 10, pp_word("LRL"), sink);
     pp_pair<PP_F_LRL_, 0, true, PP_VUT, 3>(S, in, a, 14, pp_word("LRL"), sink);
     pp_pair<PP_F_LRL_, 2, false, PP_TUV, 3>(S, in, b, 10, pp_word("LRL"), sink);
     pp_pair<PP_F_LRL_, 2, true, PP_VUT, 3>(S, in, b, 14, pp_word("LRL"), sink);
   }
-  {  // cccc :366-406 -- 18..25
+  if constexpr (FAM == 3) {  // cccc :366-406 -- 18..25
     PpWordSet<4> a, b;
     pp_pair<PP_F_LRLRN_, 0, false, PP_T_U_NU_V, 4>(S, in, a, 18, pp_word("LRLR"), sink);
     pp_pair<PP_F_LRLRP_, 0, false, PP_T_U_U_V, 4>(S, in, a, 22, pp_word("LRLR"), sink);
     pp_pair<PP_F_LRLRN_, 2, false, PP_T_U_NU_V, 4>(S, in, b, 18, pp_word("LRLR"), sink);
     pp_pair<PP_F_LRLRP_, 2, false, PP_T_U_U_V, 4>(S, in, b, 22, pp_word("LRLR"), sink);
   }
-  {  // ccsc :440-524 -- 26..41
+  if constexpr (FAM == 4) {  // ccsc :440-524 -- 26..33
     PpWordSet<4> a, b, c, d;
     pp_pair<PP_F_LRSL_, 0, false, PP_T_H_U_V, 4>(S, in, a, 26, pp_word("LRSL"), sink);
     pp_pair<PP_F_LRSL_, 2, false, PP_T_H_U_V, 4>(S, in, b, 26, pp_word("LRSL"), sink);
     pp_pair<PP_F_LRSR_, 0, false, PP_T_H_U_V, 4>(S, in, c, 30, pp_word("LRSR"), sink);
     pp_pair<PP_F_LRSR_, 2, false, PP_T_H_U_V, 4>(S, in, d, 30, pp_word("LRSR"), sink);
   }
-  {
+  if constexpr (FAM == 5) {  // ccsc, backwards -- 34..41
     PpWordSet<4> a, b, c, d;
     pp_pair<PP_F_LRSL_, 0, true, PP_V_U_H_T, 4>(S, in, a, 34, pp_word("LSRL"), sink);
     pp_pair<PP_F_LRSL_, 2, true, PP_V_U_H_T, 4>(S, in, b, 34, pp_word("LSRL"), sink);
     pp_pair<PP_F_LRSR_, 0, true, PP_V_U_H_T, 4>(S, in, c, 38, pp_word("RSRL"), sink);
     pp_pair<PP_F_LRSR_, 2, true, PP_V_U_H_T, 4>(S, in, d, 38, pp_word("RSRL"), sink);
   }
-  {  // ccscc :544-580 -- 42..45
+  if constexpr (FAM == 6) {  // ccscc :544-580 -- 42..45
     PpWordSet<5> a, b;
     pp_pair<PP_F_LRSLR_, 0, false, PP_T_H_U_H_V, 5>(S, in, a, 42, pp_word("LRSLR"), sink);
     pp_pair<PP_F_LRSLR_, 2, false, PP_T_H_U_H_V, 5>(S, in, b, 42, pp_word("LRSLR"), sink);
   }
+}
+
+// generate_path, :707-725: the families in the reference's order.
+template <class Sink>
+__device__ __forceinline__ void pp_rs_generate(double sx, double sy, double syaw, double gx, double gy,
+                                               double gyaw, double maxc, PpRsState& S, Sink& sink) {
+  const PpRsInput in = pp_rs_input(sx, sy, syaw, gx, gy, gyaw, maxc);
+  pp_rs_family<0>(in, S, sink);
+  pp_rs_family<1>(in, S, sink);
+  pp_rs_family<2>(in, S, sink);
+  pp_rs_family<3>(in, S, sink);
+  pp_rs_family<4>(in, S, sink);
+  pp_rs_family<5>(in, S, sink);
+  pp_rs_family<6>(in, S, sink);
 }
 
 #endif

@@ -312,9 +312,13 @@ __host__ __device__ inline double rs_cost(const double* len, uint32_t word, int 
   return cost;
 }
 
-// ------------------------------------------------------------------ K4: analytic shot, one wave per pair
+// ------------------------------------------------------------------ K4: analytic shot, one workgroup per pair
+// (four waves share the sampled poses of a pair, so a lone shot -- the tail of a planner batch --
+// takes a quarter of the time)
 
-__global__ void __launch_bounds__(64)
+constexpr int kShotThreads = 256;
+
+__global__ void __launch_bounds__(kShotThreads)
 k_rs_shot(uint32_t n, const double* __restrict__ sx, const double* __restrict__ sy,
           const double* __restrict__ syaw, double maxc, double step_size, uint32_t check_step,
           PpCostParams cp, const PpRsCand* __restrict__ cands, const PpRsPair* __restrict__ pairs,
@@ -363,7 +367,7 @@ k_rs_shot(uint32_t n, const double* __restrict__ sx, const double* __restrict__ 
   const double x0 = sx[pair], y0 = sy[pair], yaw0 = syaw[pair];
   double s0, c0;
   sincos(yaw0, &s0, &c0);
-  for (uint32_t t = lane; t < ntask; t += 64) {
+  for (uint32_t t = lane; t < ntask; t += kShotThreads) {
     int p = 0;
     for (int k = 1; k < np; ++k)
       if (task_end[k] <= t) p = k;
@@ -566,7 +570,7 @@ void pp_rs_shot_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, ui
   if (n == 0) return;
   PpFootprint f = pp_make_footprint(conf);
   uint32_t cs = (uint32_t)std::min<uint64_t>(conf->collision_check_step, 0x7fffffffu);
-  hipLaunchKernelGGL(k_rs_shot, dim3(n), dim3(64), 0, ctx->stream, n, d_q, d_q + n, d_q + 2 * (size_t)n,
+  hipLaunchKernelGGL(k_rs_shot, dim3(n), dim3(kShotThreads), 0, ctx->stream, n, d_q, d_q + n, d_q + 2 * (size_t)n,
                      maxc, conf->move_step, cs, cost_params(conf), d_cands, d_pairs, f, map->lat,
                      map->bk, map->lattice ? 1 : 0, d_out);
 }

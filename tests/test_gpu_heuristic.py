@@ -150,3 +150,59 @@ def test_wavefront_rectangular_and_fixpoint_property_large(ctx):
     best[gx, gy] = 0.0
     assert bool(((best == d) | (torch.isinf(best) & torch.isinf(d))).all())
     assert int(torch.isfinite(d).sum()) > xw * yw // 2
+
+
+def _fixpoint_violations(d, d_obs, gx, gy):
+    """Cells where d is not min over neighbours of (d[n] + w), evaluated on the device."""
+    import torch
+    xw, yw = d.shape
+    inf = float("inf")
+    p = torch.nn.functional.pad(d, (1, 1, 1, 1), value=inf)
+    best = torch.full_like(d, inf)
+    s2 = math.hypot(1.0, 1.0)
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            if dx == 0 and dy == 0:
+                continue
+            w = 1.0 if dx == 0 or dy == 0 else s2
+            best = torch.minimum(best, p[1 + dx:1 + dx + xw, 1 + dy:1 + dy + yw] + w)
+    del p
+    best[0, :] = inf
+    best[:, 0] = inf
+    best = torch.where(d_obs == 0, best, torch.full_like(best, inf))
+    best[gx, gy] = 0.0
+    bad = ~((best == d) | (torch.isinf(best) & torch.isinf(d)))
+    return int(bad.sum())
+
+
+def test_wavefront_full_size_16384_fixpoint(ctx):
+    """The 16384 x 16384 benchmark grid: result is the relaxation's fixpoint, 0 at the goal, and
+    most of the free space is reached."""
+    import torch
+    n = 16384
+    obs, gx, gy = W.wavefront_obsmap(n, 0.2)
+    d_obs = torch.from_numpy(obs).cuda()
+    cost = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    api.wavefront_dev(ctx, d_obs, gx, gy, cost)
+    ctx.synchronize()
+    assert float(cost[gx, gy]) == 0.0
+    assert _fixpoint_violations(cost, d_obs, gx, gy) == 0
+    assert int(torch.isfinite(cost).sum()) > 0.7 * n * n
+
+
+def test_relax_band_does_not_change_the_result(ctx):
+    """The scheduling knob only reorders the relaxation."""
+    import torch
+    obs, gx, gy = W.wavefront_obsmap(700, 0.25, seed=123)
+    d_obs = torch.from_numpy(obs).cuda()
+    outs = []
+    for band in (1.0, 64.0, 1.0e9):
+        assert ctx.lib.pp_ctx_set_relax_band(ctx.h, band) == 0
+        cost = torch.empty((700, 700), dtype=torch.float64, device="cuda")
+        api.wavefront_dev(ctx, d_obs, gx, gy, cost)
+        ctx.synchronize()
+        outs.append(cost.cpu().numpy())
+    assert ctx.lib.pp_ctx_set_relax_band(ctx.h, 64.0) == 0
+    st, exp = O.wavefront(obs, gx, gy)
+    for o in outs:
+        assert (o.view(np.uint64) == exp.view(np.uint64)).all()

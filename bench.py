@@ -34,6 +34,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 BYTES_PER_POSE = 25.0
 BYTES_PER_PAIR = 104.0
 BYTES_PER_CELL = 9.0
+BYTES_PER_PRIMITIVE = 57.0 + 48.0 / 78.0  # out: 7 x 8 B + 1 flag byte; in: 48 B per parent over 78
 
 
 def parse():
@@ -41,11 +42,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="collision", choices=["collision", "rs", "wavefront", "queries"])
+    ap.add_argument("--workload", default="collision", choices=["collision", "rs", "wavefront", "queries", "expand"])
     ap.add_argument("--poses", type=int, default=1 << 24)
     ap.add_argument("--grid", type=int, default=2048)
     ap.add_argument("--pairs", type=int, default=1 << 20)
     ap.add_argument("--cells", type=int, default=16384, help="wavefront grid edge")
+    ap.add_argument("--parents", type=int, default=1 << 18, help="expand workload: parent nodes per GPU")
     ap.add_argument("--queries", type=int, default=4096)
     ap.add_argument("--map", type=int, default=4096, help="queries workload map edge")
     ap.add_argument("--goals", type=int, default=64, help="distinct goals the queries share")
@@ -146,6 +148,30 @@ def main():
                                          npaths.data_ptr(), best.data_ptr(), words.data_ptr(),
                                          rflags.data_ptr())
             assert st == 0, st
+    elif args.workload == "expand":
+        # calc_next_node for every primitive of n parents (free poses on the collision workload's grid)
+        occ = W.occupancy_grid(args.grid, 0.01)
+        omap = api.ObstacleMap(ctx, raster=occ)
+        n = args.parents
+        x, y, yaw = W.random_poses(n, args.grid, start=rank * n)
+        steer, _ = api.calc_motion_set(conf)
+        P = len(steer)
+        dpx, dpy, dpyaw = (torch.from_numpy(a).to(dev) for a in (x, y, yaw))
+        dpdir = torch.ones(n, dtype=torch.int64, device=dev)
+        dps = torch.zeros(n, dtype=torch.float64, device=dev)
+        dpc = torch.zeros(n, dtype=torch.float64, device=dev)
+        eout = {k: torch.zeros(n * P, dtype=(torch.uint8 if k == "valid" else torch.int64 if k in
+                                             ("xind", "yind", "yawind") else torch.float64), device=dev)
+                for k in ("valid", "xind", "yind", "yawind", "cost", "end_x", "end_y", "end_yaw")}
+        units, bytes_per_unit = n * P, BYTES_PER_PRIMITIVE
+        metric, unit = "motion_primitive_rollouts_per_sec", "primitives/s"
+        wl = {"workload": f"calc_next_node: {n} parents/GPU x {P} primitives (11-pose rollout, 3 poses "
+                          f"collision-checked) on a {args.grid}x{args.grid} grid (Bernoulli 0.01)",
+              "parents_per_gpu": n, "primitives": P, "parallelism": f"parent-sharded x{world}"}
+        dtype, kernel = "f64", "k_expand"
+
+        def step():
+            api.expand_dev(ctx, omap, conf, dpx, dpy, dpyaw, dpdir, dps, dpc, eout)
     elif args.workload == "wavefront":
         from path_planner_amd import tiled
         ncell = args.cells
@@ -286,6 +312,18 @@ def main():
             dt = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": ns / dt, "unit": unit, "cores": 1, "kind": "port",
                                    "sample": f"first {ns} pairs, CPU oracle generate_path + argmin"}
+        elif args.workload == "expand":
+            ns = args.cpu_sample or min(n, 1 << 15)
+            ox, oy = W.raster_to_points(occ)
+            om = O.OracleMap(ox, oy)
+            t0 = time.perf_counter()
+            st, eo = om.expand(conf, x[:ns], y[:ns], yaw[:ns], np.ones(ns, np.int64), np.zeros(ns), np.zeros(ns))
+            dt = time.perf_counter() - t0
+            gv = eout["valid"][: ns * P].cpu().numpy()
+            mism = int((((gv & 1) != (eo["valid"] & 1)) & ((gv & 2) == 0)).sum())
+            out["cpu_baseline"] = {"value": ns * P / dt, "unit": unit, "cores": 1, "kind": "port",
+                                   "sample": f"first {ns} parents, CPU oracle calc_next_node",
+                                   "valid_mismatches_vs_gpu": mism}
         elif args.workload == "queries":
             ns = args.cpu_sample or 16
             ox, oy = W.raster_to_points(occ)

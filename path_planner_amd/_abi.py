@@ -142,6 +142,8 @@ def load_library(path=None):
         "pp_motion_set": (C.c_int32, [cfg, d, d, C.c_uint64, u64]),
         "pp_expand_batch": (C.c_int32, [vp, vp, cfg, C.c_uint64, d, d, d, i64, d, d,
                                         C.POINTER(ExpandOut)]),
+        "pp_expand_batch_dev": (C.c_int32, [vp, vp, cfg, C.c_uint64, vp, vp, vp, vp, vp, vp,
+                                            C.POINTER(ExpandOut)]),
         "pp_rollout_points": (C.c_int32, [vp, cfg, C.c_double, C.c_double, C.c_double, C.c_double,
                                           C.c_double, d, d, d, C.c_uint64, u64]),
         "pp_heuristic": (C.c_int32, [vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, d,

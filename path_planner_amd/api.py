@@ -154,6 +154,21 @@ def expand(ctx, omap, conf, px, py, pyaw, pdir, psteer, pcost):
     return out
 
 
+def expand_dev(ctx, omap, conf, px, py, pyaw, pdir, psteer, pcost, out):
+    """expand() on torch CUDA tensors: parents (float64 / int64 pdir) and out = dict of n*P tensors
+    valid (uint8), xind, yind (int64 storage of u64), yawind (int64), cost, end_x, end_y, end_yaw."""
+    vp = C.c_void_p
+    s = A.ExpandOut(C.cast(vp(out["valid"].data_ptr()), A.c_u8_p),
+                    C.cast(vp(out["xind"].data_ptr()), A.c_u64_p), C.cast(vp(out["yind"].data_ptr()), A.c_u64_p),
+                    C.cast(vp(out["yawind"].data_ptr()), A.c_i64_p), C.cast(vp(out["cost"].data_ptr()), A.c_double_p),
+                    C.cast(vp(out["end_x"].data_ptr()), A.c_double_p),
+                    C.cast(vp(out["end_y"].data_ptr()), A.c_double_p),
+                    C.cast(vp(out["end_yaw"].data_ptr()), A.c_double_p))
+    _chk(ctx.lib.pp_expand_batch_dev(ctx.h, omap.h, C.byref(conf), px.numel(), px.data_ptr(), py.data_ptr(),
+                                     pyaw.data_ptr(), pdir.data_ptr(), psteer.data_ptr(), pcost.data_ptr(),
+                                     C.byref(s)), "pp_expand_batch_dev")
+
+
 def rollout_points(ctx, conf, x0, y0, yaw0, u, d):
     cap = 1 << 16
     x, y, yaw = np.zeros(cap), np.zeros(cap), np.zeros(cap)

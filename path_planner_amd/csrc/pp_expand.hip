@@ -255,6 +255,44 @@ extern "C" int32_t pp_expand_batch(pp_ctx* ctx, const pp_map* map, const pp_conf
   return PP_OK;
 }
 
+extern "C" int32_t pp_expand_batch_dev(pp_ctx* ctx, const pp_map* map, const pp_config* conf,
+                                       uint64_t n, const double* d_px, const double* d_py,
+                                       const double* d_pyaw, const int64_t* d_pdir,
+                                       const double* d_psteer, const double* d_pcost,
+                                       const pp_expand_out* d_out) {
+  if (!ctx || !map || !conf || !d_out) return PP_ERR_INVALID;
+  if (map->ox.empty()) return PP_ERR_EMPTY_MAP;
+  if (!map->finite) return PP_ERR_NONFINITE;
+  if (n == 0) return PP_OK;
+  if (!d_px || !d_py || !d_pyaw || !d_pdir || !d_psteer || !d_pcost) return PP_ERR_INVALID;
+  if (!d_out->valid || !d_out->xind || !d_out->yind || !d_out->yawind || !d_out->cost || !d_out->end_x ||
+      !d_out->end_y || !d_out->end_yaw)
+    return PP_ERR_INVALID;
+  PpExpandPlan plan;
+  int32_t st = pp_expand_prepare(ctx, map, conf, &plan);
+  if (st != PP_OK) return st;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  // the motion table (steer, direction, tan(steer)) is the only thing staged by the library
+  st = pp_scratch_reserve(ctx, al256(plan.motion.size() * 8));
+  if (st != PP_OK) return st;
+  double* d_mot = (double*)ctx->scratch;
+  PP_HIP(ctx, hipMemcpyAsync(d_mot, plan.motion.data(), plan.motion.size() * 8, hipMemcpyHostToDevice,
+                             ctx->stream));
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // plan.motion is a local
+  PpExpandDev o{};
+  o.valid = d_out->valid;
+  o.xind = d_out->xind;
+  o.yind = d_out->yind;
+  o.yawind = d_out->yawind;
+  o.cost = d_out->cost;
+  o.end_x = d_out->end_x;
+  o.end_y = d_out->end_y;
+  o.end_yaw = d_out->end_yaw;
+  pp_expand_launch(ctx, map, plan, n, d_px, d_py, d_pyaw, d_pdir, d_psteer, d_pcost, d_mot, o);
+  PP_HIP(ctx, hipGetLastError());
+  return PP_OK;
+}
+
 int32_t pp_rollout_points_batch(pp_ctx* ctx, const pp_config* conf, uint32_t n,
                                 const double* in5 /* x,y,yaw,u,d per item */, double* x, double* y,
                                 double* yaw, uint32_t* nlist_out) {

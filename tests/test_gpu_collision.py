@@ -173,3 +173,29 @@ def test_rollout_points_vs_oracle(ctx):
         assert len(x) == 11
         assert (yaw == eyaw).all()
         assert np.allclose(x, ex, rtol=0, atol=1e-13) and np.allclose(y, ey, rtol=0, atol=1e-13)
+
+
+def test_expand_dev_matches_host_form(ctx):
+    """pp_expand_batch_dev (device pointers) against pp_expand_batch (host pointers)."""
+    import torch
+    occ = W.occupancy_grid(256, 0.02, seed=17)
+    m = api.ObstacleMap(ctx, raster=occ)
+    n = 3000
+    x, y, yaw = W.random_poses(n, 256, seed=91)
+    pdir = np.where(np.arange(n) % 3 == 0, -1, 1).astype(np.int64)
+    ps = np.linspace(-0.5, 0.5, n)
+    pc = np.linspace(0.0, 100.0, n)
+    host = api.expand(ctx, m, CONF, x, y, yaw, pdir, ps, pc)
+    P = len(host["valid"]) // n
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = {k: torch.zeros(n * P, dtype=(torch.uint8 if k == "valid" else torch.int64 if k in
+                                        ("xind", "yind", "yawind") else torch.float64), device="cuda")
+           for k in ("valid", "xind", "yind", "yawind", "cost", "end_x", "end_y", "end_yaw")}
+    api.expand_dev(ctx, m, CONF, t(x), t(y), t(yaw), t(pdir), t(ps), t(pc), out)
+    ctx.synchronize()
+    for k, v in out.items():
+        got = v.cpu().numpy()
+        exp = host[k]
+        if exp.dtype == np.uint64:
+            exp = exp.view(np.int64)
+        assert (got == exp).all(), k

@@ -163,20 +163,24 @@ static int32_t build_lattice(pp_ctx* ctx, pp_map* m, const std::vector<int64_t>&
   int64_t x0 = (lo_x & ~(int64_t)31) - 32, y0 = (lo_y & ~(int64_t)31) - 32;
   int64_t nx = ((hi_x - x0) / 32 + 2) * 32, ny = ((hi_y - y0) / 32 + 2) * 32;
   if (nx > (1 << 24) || ny > (1 << 24)) return PP_ERR_UNSUPPORTED;
-  int32_t nstrips = (int32_t)(nx / 32), nbrows = (int32_t)(ny / 4);
-  size_t nwords = (size_t)nstrips * (size_t)nbrows * 4;
+  const int32_t ntx = (int32_t)(nx / 16), nty = (int32_t)(ny / 16);
+  const size_t nwords = (size_t)ntx * (size_t)nty * 32;
   if (nwords > ((size_t)1 << 33)) return PP_ERR_UNSUPPORTED;
   std::vector<uint32_t> words(nwords, 0u);
   for (size_t i = 0; i < ix.size(); ++i) {
-    int64_t gx = ix[i] - x0, gy = iy[i] - y0;
-    size_t word = ((size_t)(gx >> 5) * (size_t)nbrows + (size_t)(gy >> 2)) * 4 + (size_t)(gy & 3);
-    words[word] |= 1u << (gx & 31);
+    const int64_t gx = ix[i] - x0, gy = iy[i] - y0;
+    // the (up to) four overlapping tiles that hold the cell
+    for (int64_t tx = (gx >> 4) - 1; tx <= (gx >> 4); ++tx)
+      for (int64_t ty = (gy >> 4) - 1; ty <= (gy >> 4); ++ty) {
+        if (tx < 0 || ty < 0) continue;
+        words[((size_t)tx * (size_t)nty + (size_t)ty) * 32 + (size_t)(gy - 16 * ty)] |= 1u << (gx - 16 * tx);
+      }
   }
   PP_HIP(ctx, hipMalloc((void**)&m->d_tiles, nwords * sizeof(uint32_t)));
   PP_HIP(ctx, hipMemcpy(m->d_tiles, words.data(), nwords * sizeof(uint32_t), hipMemcpyHostToDevice));
-  m->lat.blocks = m->d_tiles;
-  m->lat.nstrips = nstrips;
-  m->lat.nbrows = nbrows;
+  m->lat.tiles = m->d_tiles;
+  m->lat.ntx = ntx;
+  m->lat.nty = nty;
   m->lat.nx = (int32_t)nx;
   m->lat.ny = (int32_t)ny;
   m->lat.x0 = x0;

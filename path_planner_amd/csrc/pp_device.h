@@ -50,8 +50,10 @@ __device__ __forceinline__ void pp_footprint_centre(double x, double y, double c
 // ---------------------------------------------------------------------------------------------
 // Bit-packed lattice (layout: PpLattice in pp_internal.h).
 
-__device__ __forceinline__ uint4 pp_lattice_block(const PpLattice& g, int col, int brow) {
-  return g.blocks[(size_t)(col >> 5) * (size_t)g.nbrows + (size_t)brow];
+// Columns xb .. xb + 15 (xb a multiple of 16) of grid row y, in the low 16 bits.
+__device__ __forceinline__ unsigned pp_lattice_row16(const PpLattice& g, int xb, int y) {
+  const uint32_t* w = (const uint32_t*)(g.tiles + ((size_t)(xb >> 4) * (size_t)g.nty + (size_t)(y >> 4)) * 8);
+  return w[y & 15] & 0xFFFFu;
 }
 
 // Exhaustive form: the exact predicate on every occupied cell of the rotated rectangle's
@@ -69,12 +71,10 @@ __device__ __forceinline__ unsigned pp_lattice_scan_exact(double cx, double cy, 
   int ix0 = (int)fx0, ix1 = (int)fx1, iy0 = (int)fy0, iy1 = (int)fy1;
   bool amb = false, ahit = false;
   for (int y = iy0; y <= iy1; ++y) {
-    for (int xb = ix0 & ~31; xb <= ix1; xb += 32) {
-      uint4 blk = pp_lattice_block(g, xb, y >> 2);
-      int r = y & 3;
-      unsigned w = r == 0 ? blk.x : r == 1 ? blk.y : r == 2 ? blk.z : blk.w;
-      int c0 = max(ix0 - xb, 0), c1 = min(ix1 - xb, 31);
-      unsigned m = w & (0xFFFFFFFFu >> (31 - c1)) & (0xFFFFFFFFu << c0);
+    for (int xb = ix0 & ~15; xb <= ix1; xb += 16) {
+      unsigned w = pp_lattice_row16(g, xb, y);
+      int c0 = max(ix0 - xb, 0), c1 = min(ix1 - xb, 15);
+      unsigned m = w & (0xFFFFu >> (15 - c1)) & (0xFFFFu << c0);
       while (m) {
         int b = __builtin_ctz(m);
         m &= m - 1;
@@ -95,8 +95,8 @@ __device__ __forceinline__ unsigned pp_lattice_scan_exact(double cx, double cy, 
 // (f.scan_ok).  Everything here is a FILTER around the exact predicate: it may only answer when
 // the exact fp64 predicate (under any libm accurate to a few ulp) provably agrees.
 //
-// The window is the 13 columns floor(gx)-6 .. +6 by the 16 rows of the four block rows covering
-// floor(gy)-6 .. +6, in window coordinates (origin ix0, yb).  Two rectangles around the true
+// The window is the 13 columns floor(gx)-6 .. +6 by the 16 rows of the four block rows (uint4 of
+// the tile) covering floor(gy)-6 .. +6, in window coordinates (origin ix0, yb).  Two rectangles around the true
 // footprint rectangle are used, both from fp32 sin/cos (error < 2e-7) and fp32 arithmetic
 // (error < 5e-5 cells at window coordinates below 32):
 //   * inflated by 2.5e-4 on every side (f.scan_lo, f.scan_wo): rasterised row by row, window
@@ -132,9 +132,8 @@ __device__ __forceinline__ unsigned pp_bfm(unsigned width, unsigned offset) {
 // Four window rows (one block row).  `key` keeps one candidate: (occupied bits under the row
 // mask) << 4 | window row, maximised over rows, so key >= 16 iff some row had a candidate.
 template <int J0>
-__device__ __forceinline__ unsigned pp_scan_rows4(const PpScan& q, uint4 lb, uint4 rb, unsigned key) {
+__device__ __forceinline__ unsigned pp_scan_rows4(const PpScan& q, uint4 lb, unsigned key) {
   const unsigned lw[4] = {lb.x, lb.y, lb.z, lb.w};
-  const unsigned rw[4] = {rb.x, rb.y, rb.z, rb.w};
   unsigned k[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -147,7 +146,7 @@ __device__ __forceinline__ unsigned pp_scan_rows4(const PpScan& q, uint4 lb, uin
     const float wf = __builtin_floorf(hi) - cl;  // cells cl .. floor(hi) - 1 (xR1 carries the +1)
     // empty row: wf <= 0 -> width 0 -> mask 0 whatever the offset's low bits are; width <= 24
     const unsigned mask = pp_bfm(pp_cvt_u32_sat(wf), pp_cvt_u32_sat(cl));
-    const unsigned bits = __builtin_amdgcn_alignbit(rw[r], lw[r], q.sh);
+    const unsigned bits = lw[r] >> q.sh;  // q.sh <= 15: the 13 window columns stay inside the word
     k[r] = ((bits & mask) << 4) | (unsigned)(J0 + r);
   }
   return max(max(key, k[0]), max(max(k[1], k[2]), k[3]));
@@ -188,7 +187,7 @@ __device__ __forceinline__ int pp_lattice_filter(double x, double y, float cf, f
   const double bxf = floor(gx), byf = floor(gy);
   const int ibx = (int)bxf, iby = (int)byf;
   const float fx = (float)(gx - bxf), fy = (float)(gy - byf);
-  const int ix0 = ibx - 6, ytop = iby - 6, o = ytop & 3, yb = ytop - o;
+  const int ix0 = ibx - 6, ytop = iby - 6, o = ytop & 3;  // window rows start at yb = ytop - o
   const float wx = 6.0f + fx, wy = (float)(6 + o) + fy;  // centre in window coordinates
 
   const float acf = __builtin_fabsf(cf), asf = __builtin_fabsf(sf);
@@ -208,27 +207,20 @@ __device__ __forceinline__ int pp_lattice_filter(double x, double y, float cf, f
   const float cden = (acf < 1e-30f) ? __builtin_copysignf(1e-30f, cf) : cf;
   q.m1 = cf * __builtin_amdgcn_rcpf(sden);
   q.m2 = -sf * __builtin_amdgcn_rcpf(cden);
-  q.sh = (unsigned)ix0 & 31u;
+  q.sh = (unsigned)ix0 & 15u;
 
-  const bool two = ((ix0 + 12) >> 5) != (ix0 >> 5);
-  const uint4* base = g.blocks + ((size_t)(ix0 >> 5) * (size_t)g.nbrows + (size_t)(yb >> 2));
-  const uint4 zero = make_uint4(0, 0, 0, 0);
-  uint4 l1 = base[1], l2 = base[2], r1 = zero, r2 = zero;
-  if (two) {
-    r1 = base[g.nbrows + 1];
-    r2 = base[g.nbrows + 2];
-  }
+  // the tile that starts at or before the window's low corner holds all of it: rows ytop & 15 ..
+  // + 12 < 32, columns q.sh .. + 12 < 32; the four block rows from yb are uint4 (yb & 15) >> 2 .. + 3
+  const uint4* base = g.tiles + (((size_t)(ix0 >> 4) * (size_t)g.nty + (size_t)(ytop >> 4)) * 8 +
+                                 (size_t)((ytop & 15) >> 2));
+  const uint4 l1 = base[1], l2 = base[2];
   unsigned key = 0;
-  key = pp_scan_rows4<4>(q, l1, r1, key);
-  key = pp_scan_rows4<8>(q, l2, r2, key);
+  key = pp_scan_rows4<4>(q, l1, key);
+  key = pp_scan_rows4<8>(q, l2, key);
   if (key < 16) {
-    uint4 l0 = base[0], l3 = base[3], r0 = zero, r3 = zero;
-    if (two) {
-      r0 = base[g.nbrows];
-      r3 = base[g.nbrows + 3];
-    }
-    key = pp_scan_rows4<0>(q, l0, r0, key);
-    key = pp_scan_rows4<12>(q, l3, r3, key);
+    const uint4 l0 = base[0], l3 = base[3];
+    key = pp_scan_rows4<0>(q, l0, key);
+    key = pp_scan_rows4<12>(q, l3, key);
     if (key < 16) return 0;
   }
   // one candidate cell against the deflated rectangle

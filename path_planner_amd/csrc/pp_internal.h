@@ -30,15 +30,17 @@ struct PpFootprint {
 };
 
 // Occupancy of an integer-lattice obstacle set, bit-packed for gather locality.
-//   block = 32 columns x 4 rows = 16 B (one dwordx4 gather): word r = row r, bit = column & 31
-//   strip = the blocks of one 32-column band, stored contiguously bottom to top, so the block
-//           rows a footprint window needs are consecutive uint4 (8 of them per 128-B line)
-//   block of cell (x, y) = blocks[(x >> 5) * nbrows + (y >> 2)]
+//   tile  = 32 columns x 32 rows = 128 B = one cache line: word r = row r, bit = column
+//   tiles start every 16 cells in both directions, so they overlap and every cell is stored in
+//   four of them: tile (tx, ty) covers columns [16 tx, 16 tx + 32) and rows [16 ty, 16 ty + 32).
+//   Any window of up to 17 x 17 cells lies inside the tile that starts at or before its low
+//   corner, so a footprint test touches exactly one line however the window falls.
+//   tile (tx, ty) = tiles[(tx * nty + ty) * 8 .. + 8]  (uint4 k of a tile = rows 4k .. 4k + 3)
 // Cell (cx, cy) in lattice coordinates maps to grid coordinates (cx - x0, cy - y0); the grid is
 // padded with a ring of 32 empty cells so windows near the rim need no per-load bounds test.
 struct PpLattice {
-  const uint4* blocks;
-  int32_t nstrips, nbrows;
+  const uint4* tiles;
+  int32_t ntx, nty;
   int32_t nx, ny;      // cells including padding (multiples of 32)
   int64_t x0, y0;      // lattice coordinate of grid cell (0, 0)
 };

@@ -53,7 +53,9 @@ __device__ inline void write_word(pp_rs_word* o, uint32_t word, int n, const dou
   o->pad_[0] = o->pad_[1] = 0;
 }
 
-__global__ void __launch_bounds__(128)
+// Two waves per SIMD measured best for this register-hungry kernel (1.68 G pairs/s; the compiler's
+// own choice of one wave gives 1.1, three waves spill and give 1.4, four 0.97).
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_rs_batch(uint64_t n, const double* __restrict__ sx, const double* __restrict__ sy,
            const double* __restrict__ syaw, const double* __restrict__ gx,
            const double* __restrict__ gy, const double* __restrict__ gyaw, double maxc,

@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="collision", choices=["collision", "rs", "wavefront", "queries", "expand"])
+    ap.add_argument("--workload", default="collision", choices=["collision", "rs", "wavefront", "queries", "expand", "analytic"])
     ap.add_argument("--poses", type=int, default=1 << 24)
     ap.add_argument("--grid", type=int, default=2048)
     ap.add_argument("--pairs", type=int, default=1 << 20)
@@ -172,6 +172,26 @@ def main():
 
         def step():
             api.expand_dev(ctx, omap, conf, dpx, dpy, dpyaw, dpdir, dps, dpc, eout)
+    elif args.workload == "analytic":
+        # analystic_expansion for n (node, goal) pairs: all words, cost order, sampled poses of each
+        # path collision-checked until one is free.  Host-pointer entry point: the 48 B in / 76 B out
+        # per pair cross PCIe inside the timed region (negligible next to the kernels).
+        occ = W.occupancy_grid(args.grid, 0.01)
+        omap = api.ObstacleMap(ctx, raster=occ)
+        n = args.pairs // 4
+        q0, q1 = W.rs_pairs(n, start=rank * n, extent=200.0)
+        q0[:, :2] += args.grid / 2 - 100.0
+        q1[:, :2] += args.grid / 2 - 100.0
+        units, bytes_per_unit = n, 124.0
+        metric, unit = "analytic_expansion_shots_per_sec", "shots/s"
+        wl = {"workload": f"analytic expansion: {n} (node, goal) pairs/GPU within a 200 m box on a "
+                          f"{args.grid}x{args.grid} grid (Bernoulli 0.01), demo car and costs",
+              "pairs_per_gpu": n, "parallelism": f"pair-sharded x{world}"}
+        dtype, kernel = "f64", "k_rs_words+k_rs_shot"
+        last = {}
+
+        def step():
+            last["r"] = api.analytic_expansion(ctx, omap, conf, q0, q1)
     elif args.workload == "wavefront":
         from path_planner_amd import tiled
         ncell = args.cells
@@ -324,6 +344,21 @@ def main():
             out["cpu_baseline"] = {"value": ns * P / dt, "unit": unit, "cores": 1, "kind": "port",
                                    "sample": f"first {ns} parents, CPU oracle calc_next_node",
                                    "valid_mismatches_vs_gpu": mism}
+        elif args.workload == "analytic":
+            ns = args.cpu_sample or min(n, 4096)
+            ox, oy = W.raster_to_points(occ)
+            om = O.OracleMap(ox, oy)
+            t0 = time.perf_counter()
+            st, efound, eidx, enp, ewords, ecost = om.analytic(conf, q0[:ns], q1[:ns])
+            dt = time.perf_counter() - t0
+            gfound, gidx = last["r"][0][:ns], last["r"][1][:ns]
+            clean = (gfound & 2) == 0
+            mism = int((((gfound & 1) != (efound & 1)) & clean).sum() +
+                       (((gfound & 1) == 1) & ((efound & 1) == 1) & (gidx != eidx) & clean).sum())
+            out["cpu_baseline"] = {"value": ns / dt, "unit": unit, "cores": 1, "kind": "port",
+                                   "sample": f"first {ns} pairs, CPU oracle analystic_expansion",
+                                   "mismatches_vs_gpu": mism,
+                                   "found_fraction": float((efound & 1).mean())}
         elif args.workload == "queries":
             ns = args.cpu_sample or 16
             ox, oy = W.raster_to_points(occ)

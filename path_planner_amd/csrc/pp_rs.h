@@ -40,7 +40,7 @@ void pp_rs_words_launch(pp_ctx* ctx, uint64_t n, const double* d_q, double maxc,
                         PpRsPair* d_pairs);
 void pp_rs_shot_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, uint32_t n,
                        const double* d_q, double maxc, const PpRsCand* d_cands,
-                       const PpRsPair* d_pairs, PpShotOut* d_out);
+                       const PpRsPair* d_pairs, PpShotOut* d_out, pp_rs_word* d_words = nullptr);
 int32_t pp_rs_single(pp_ctx* ctx, const double q[6], double maxc, double step_size, int only_rank,
                      int32_t* n_paths, pp_rs_word* words, uint64_t* traj_off, double* traj_x,
                      double* traj_y, double* traj_yaw, int64_t* traj_dir, uint64_t traj_cap,

@@ -324,7 +324,8 @@ __global__ void __launch_bounds__(kShotThreads)
 k_rs_shot(uint32_t n, const double* __restrict__ sx, const double* __restrict__ sy,
           const double* __restrict__ syaw, double maxc, double step_size, uint32_t check_step,
           PpCostParams cp, const PpRsCand* __restrict__ cands, const PpRsPair* __restrict__ pairs,
-          PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice, PpShotOut* __restrict__ out) {
+          PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice, PpShotOut* __restrict__ out,
+          pp_rs_word* __restrict__ word_out /* optional: the accepted path's word */) {
   __shared__ PathPlan plans[PP_RS_MAX_PATHS];
   __shared__ double costs[PP_RS_MAX_PATHS];
   __shared__ uint32_t hit[PP_RS_MAX_PATHS];
@@ -412,6 +413,14 @@ k_rs_shot(uint32_t n, const double* __restrict__ sx, const double* __restrict__ 
       }
     }
     out[pair] = o;
+    if (word_out) {
+      pp_rs_word wz{};
+      if (o.path_idx >= 0) {
+        const PpRsCand c = pc[o.gen];
+        write_word(&wz, c.word, c.nseg, c.len, c.total / maxc, maxc);
+      }
+      word_out[pair] = wz;
+    }
   }
 }
 
@@ -568,13 +577,13 @@ void pp_rs_words_launch(pp_ctx* ctx, uint64_t n, const double* d_q /* 6 arrays o
 
 void pp_rs_shot_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, uint32_t n,
                        const double* d_q, double maxc, const PpRsCand* d_cands,
-                       const PpRsPair* d_pairs, PpShotOut* d_out) {
+                       const PpRsPair* d_pairs, PpShotOut* d_out, pp_rs_word* d_words) {
   if (n == 0) return;
   PpFootprint f = pp_make_footprint(conf);
   uint32_t cs = (uint32_t)std::min<uint64_t>(conf->collision_check_step, 0x7fffffffu);
   hipLaunchKernelGGL(k_rs_shot, dim3(n), dim3(kShotThreads), 0, ctx->stream, n, d_q, d_q + n, d_q + 2 * (size_t)n,
                      maxc, conf->move_step, cs, cost_params(conf), d_cands, d_pairs, f, map->lat,
-                     map->bk, map->lattice ? 1 : 0, d_out);
+                     map->bk, map->lattice ? 1 : 0, d_out, d_words);
 }
 
 extern "C" int32_t pp_rs_batch_dev(pp_ctx* ctx, uint64_t n, const double* d_sx, const double* d_sy,
@@ -855,28 +864,28 @@ extern "C" int32_t pp_analytic_batch(pp_ctx* ctx, const pp_map* map, const pp_co
   if (st != PP_OK) return st;
   PP_HIP(ctx, hipSetDevice(ctx->device));
   size_t ac = al256(n * PP_RS_MAX_PATHS * sizeof(PpRsCand)), ap = al256(n * sizeof(PpRsPair));
-  size_t ao = al256(n * sizeof(PpShotOut));
+  size_t ao = al256(n * sizeof(PpShotOut)), aw = al256(n * sizeof(pp_rs_word));
   const double* hq[6] = {sx, sy, syaw, gx, gy, gyaw};
   hipStream_t s = ctx->stream;
   // the six arrays go back to back, as the launch helpers expect
   std::vector<double> packed(6 * n);
   for (int k = 0; k < 6; ++k) std::memcpy(packed.data() + k * n, hq[k], n * 8);
-  st = pp_scratch_reserve(ctx, al256(6 * n * 8) + ac + ap + ao);
+  st = pp_scratch_reserve(ctx, al256(6 * n * 8) + ac + ap + ao + aw);
   if (st != PP_OK) return st;
   char* b = (char*)ctx->scratch;
   double* d_q = (double*)b;
   PpRsCand* d_c = (PpRsCand*)(b + al256(6 * n * 8));
   PpRsPair* d_p = (PpRsPair*)((char*)d_c + ac);
   PpShotOut* d_o = (PpShotOut*)((char*)d_p + ap);
+  pp_rs_word* d_w = (pp_rs_word*)((char*)d_o + ao);
   PP_HIP(ctx, hipMemcpyAsync(d_q, packed.data(), 6 * n * 8, hipMemcpyHostToDevice, s));
   double maxc = std::tan(conf->max_steer) / conf->car.wheel_base;  // hybrid_astar.rs:388
   pp_rs_words_launch(ctx, n, d_q, maxc, d_c, d_p);
-  pp_rs_shot_launch(ctx, map, conf, (uint32_t)n, d_q, maxc, d_c, d_p, d_o);
+  pp_rs_shot_launch(ctx, map, conf, (uint32_t)n, d_q, maxc, d_c, d_p, d_o, d_w);
   PP_HIP(ctx, hipGetLastError());
   std::vector<PpShotOut> ho(n);
-  std::vector<PpRsCand> hc(n * PP_RS_MAX_PATHS);
   PP_HIP(ctx, hipMemcpyAsync(ho.data(), d_o, n * sizeof(PpShotOut), hipMemcpyDeviceToHost, s));
-  PP_HIP(ctx, hipMemcpyAsync(hc.data(), d_c, n * PP_RS_MAX_PATHS * sizeof(PpRsCand), hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(word, d_w, n * sizeof(pp_rs_word), hipMemcpyDeviceToHost, s));
   PP_HIP(ctx, hipStreamSynchronize(s));
   int32_t ret = PP_OK;
   for (uint64_t i = 0; i < n; ++i) {
@@ -884,20 +893,9 @@ extern "C" int32_t pp_analytic_batch(pp_ctx* ctx, const pp_map* map, const pp_co
     found[i] = (uint8_t)((o.flags & 1u) | (o.flags & 2u) | (o.flags & 4u));
     path_idx[i] = o.path_idx;
     n_paths[i] = o.n_paths;
-    std::memset(&word[i], 0, sizeof(pp_rs_word));
-    rs_cost_out[i] = 0.0;
+    rs_cost_out[i] = o.path_idx >= 0 ? o.cost : 0.0;
     if (o.flags & 8u) ret = PP_ERR_NAN_COST;
     if (o.flags & 16u) ret = PP_ERR_NONFINITE;
-    if (o.path_idx >= 0) {
-      const PpRsCand& c = hc[i * PP_RS_MAX_PATHS + o.gen];
-      for (int k = 0; k < c.nseg; ++k) {
-        word[i].lengths[k] = c.len[k] / maxc;
-        word[i].ctypes[k] = pp_word_letter(c.word, k);
-      }
-      word[i].nseg = (uint8_t)c.nseg;
-      word[i].total_length = c.total / maxc;
-      rs_cost_out[i] = o.cost;
-    }
   }
   return ret;
 }

@@ -30,6 +30,8 @@ step bench_wave16384 600 python3 -u bench.py --workload wavefront --cells 16384 
 tail -1 "$O/bench_wave16384.log"
 step bench_expand 300 python3 -u bench.py --workload expand --steps 10
 tail -1 "$O/bench_expand.log"
+step bench_analytic 300 python3 -u bench.py --workload analytic --steps 5 --warmup 1
+tail -1 "$O/bench_analytic.log"
 step bench_queries 600 python3 -u bench.py --workload queries --steps 3 --warmup 1
 tail -1 "$O/bench_queries.log"
 export TMPDIR=/tmp

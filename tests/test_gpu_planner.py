@@ -154,3 +154,43 @@ def test_plan_error_paths(ctx):
     O.set_max_expansions(0)
     assert r["status"] == eo["status"] == A.PP_ERR_LIMIT
     assert (r["closed"][:300] == eo["closed"][:300]).all() or r["stats"].ambiguous
+
+
+def test_plan_batch_many_queries_on_a_large_map_vs_oracle(ctx):
+    """The many-queries workload at reduced size: 96 queries sharing 8 goals on a 1024 x 1024 map
+    with clustered wall segments; every query against the CPU oracle."""
+    occ = W.plan_map(1024)
+    ox, oy = W.raster_to_points(occ)
+    m = api.ObstacleMap(ctx, raster=occ)
+    om = O.OracleMap(ox, oy)
+    cs, cg = W.plan_queries(400, 1024, 8)
+    fs = api.collision_flags(ctx, m, CONF, cs[:, 0], cs[:, 1], cs[:, 2])
+    fg = api.collision_flags(ctx, m, CONF, cg[:, 0], cg[:, 1], cg[:, 2])
+    inside = (cs[:, 0] > 8) & (cs[:, 0] < 1015) & (cs[:, 1] > 8) & (cs[:, 1] < 1015)
+    keep = np.nonzero(inside & (fs == 0) & (fg == 0))[0][:96]
+    assert len(keep) == 96
+    starts, goals = cs[keep], cg[keep]
+    ctx.set_max_expansions(2000)
+    O.set_max_expansions(2000)
+    try:
+        r = api.plan_batch(ctx, m, CONF, starts, goals, cap=4096, closed_cap=2048)
+        bad = 0
+        for i in range(96):
+            e = om.plan(CONF, starts[i], goals[i])
+            ne = int(r["stats"][i].expansions)
+            same = (r["status"][i] == e["status"] and ne == e["stats"].expansions and
+                    (r["closed"][i, :min(ne, 2048)] == e["closed"][:2048]).all())
+            if same and e["status"] == 0:
+                L = int(r["len"][i])
+                same = (L == len(e["x"]) and abs(r["cost"][i] - e["cost"]) <= 1e-9 * abs(e["cost"]) and
+                        np.allclose(r["x"][i, :L], e["x"], rtol=1e-9, atol=1e-9) and
+                        np.allclose(r["yaw"][i, :L], e["yaw"], rtol=1e-9, atol=1e-9) and
+                        (r["dir"][i, :L] == e["dir"]).all())
+            if not same:
+                assert r["stats"][i].ambiguous, i  # only a guard-band decision may differ
+                bad += 1
+        assert bad <= 5
+        assert (r["status"] == 0).sum() >= 80
+    finally:
+        ctx.set_max_expansions(100000)
+        O.set_max_expansions(0)

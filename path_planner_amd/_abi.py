@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "csrc", "libpp_hip.so")
+LIB_PATH = os.environ.get("PP_HIP_LIB") or os.path.join(PKG_DIR, "csrc", "libpp_hip.so")
 
 PP_OK = 0
 PP_NO_PATH = 1

@@ -96,29 +96,29 @@ __global__ void k_obsmap(uint64_t n, const double* __restrict__ ox, const double
 // The reference's Dijkstra (astar.rs:153-198) computes the unique fixpoint of
 //   d[goal] = 0,  d[v] = min over valid neighbours n of fl(d[n] + w(n, v)),  w in {1, hypot(1,1)}
 // (each fl(d + w) is monotone in d, so relaxing from any upper bounds in any order converges to the
-// same bits).  The grid is cut into 32x32-cell tiles; a round relaxes every listed tile to its
+// same bits).  The grid is cut into 64x64-cell tiles; a round relaxes every listed tile to its
 // own fixpoint against the current values of the surrounding ring of cells, and a tile whose edge
-// cells moved wakes the neighbours that see them.  One wave owns one tile: each lane keeps a 4x4
-// patch in registers and sweeps it forward and backward (a two-pass chamfer transform), the
-// patches trade rim values through LDS, and the wave repeats until no cell moves.
+// cells moved wakes the neighbours that see them.  One workgroup of four waves owns one tile, a
+// wave one 32x32 quadrant of it: each lane keeps a 4x4 patch in registers and sweeps it forward
+// and backward (a two-pass chamfer transform), the patches trade rim values through LDS, and the
+// workgroup repeats until no cell moves.  A value crosses one patch per sweep, so the cost of a
+// visit is the number of patches a front has to cross times the f64 operations of a sweep (the
+// sweep is bound by VALU issue, not by latency); the larger tile halves the number of rounds a
+// front needs to cross the grid.
 //
 // Rounds are ordered by cost, Dijkstra-like at tile granularity: a woken tile carries a key (the
 // lowest value that newly appeared next to it) and is listed only once the key is within `band`
 // of the lowest pending key.  Relaxing a tile before its inputs have settled would push
 // provisional values downstream that every later correction has to chase.
 //
-// Working layout: costs live in a blocked array, one contiguous 8 KiB block per tile with the
-// 16 cells of a lane's patch interleaved across lanes (so every load is a coalesced 1 KiB), and
+// Working layout: costs live in a blocked array, one contiguous 8 KiB block per 32x32 quadrant
+// with the 16 cells of a lane's patch interleaved across lanes (so every load is a coalesced 1 KiB), and
 // the obstacle raster is folded into one mask word per lane.  The caller's dense x-major arrays
 // are packed into that layout before the rounds and unpacked after them.
 
-constexpr int kTile = 32;                    // cells per tile side
-constexpr int kPps = 8;                      // 4x4 patches per tile side
-constexpr int kRing = kPps + 2;              // patch grid plus the ring outside the tile
-constexpr int kSlot = kRing * kRing;         // doubles per rim slot
-constexpr int kWaveLds = 12 * kSlot;         // doubles of LDS per wave: the 12 rim cells of a patch
-constexpr int kWavesPerBlock = 4;
-constexpr int kBlk = kTile * kTile;          // doubles per tile block
+constexpr int kTile = 32;                    // cells per block side (one wave's quadrant of a tile)
+constexpr int kPps = 8;                      // 4x4 patches per block side
+constexpr int kBlk = kTile * kTile;          // doubles per block
 constexpr unsigned long long kInfBits = 0x7FF0000000000000ull;
 
 // LDS slot of patch cell (i, j); only cells on the patch rim are ever read by other lanes.
@@ -164,7 +164,8 @@ __device__ inline bool dense_column(const DenseView& d, int64_t x, uint32_t& pla
 struct TileGrid {
   double* blk;           // tile t at blk + t * kBlk
   uint32_t* mask;        // mask[t * 64 + lane]: bit k = cell k blocked, bit 16 + k = cell k fixed
-  uint32_t ntx, nty;     // tiles over the stored columns
+  uint32_t ntx, nty;     // 32x32 blocks over the stored columns
+  uint32_t nsx, nsy;     // scheduling tiles: 2x2 blocks = 64x64 cells, one workgroup each
 };
 
 struct TileWork {
@@ -195,8 +196,8 @@ __device__ inline double pp_max_f64(double a, double b) {
 // kbits into minkey[] of the next round.
 __device__ inline void tile_wake(const TileGrid& g, const TileWork& w, int64_t tx, int64_t ty,
                                  unsigned long long kbits) {
-  if (tx < 0 || ty < 0 || tx >= (int64_t)g.ntx || ty >= (int64_t)g.nty) return;
-  const uint32_t t = (uint32_t)tx * g.nty + (uint32_t)ty;
+  if (tx < 0 || ty < 0 || tx >= (int64_t)g.nsx || ty >= (int64_t)g.nsy) return;
+  const uint32_t t = (uint32_t)tx * g.nsy + (uint32_t)ty;
   atomicMin(&w.key[t], kbits);
   atomicOr(&w.bitmap[t >> 5], 1u << (t & 31u));
 }
@@ -325,32 +326,55 @@ __global__ void __launch_bounds__(256) k_tile_list(TileGrid g, TileWork w, uint3
   if (lane == 0 && wait != kInfBits) atomicMin(&w.minkey[(round + 1) % 3], wait);
 }
 
-__global__ void __launch_bounds__(64 * kWavesPerBlock)
+// One workgroup relaxes one 64x64 scheduling tile: its four waves own the four 32x32 blocks, the
+// patches of all four trade rim values through one LDS array, and the sweeps repeat (two block
+// barriers each) until no cell of the tile moves.
+constexpr int kSPps = 2 * kPps;              // patches per scheduling-tile side
+constexpr int kSRing = kSPps + 2;
+constexpr int kSSlot = kSRing * kSRing;      // doubles per rim slot
+constexpr int kSTile = 2 * kTile;
+
+
+__global__ void __launch_bounds__(256)
 k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
-  __shared__ double lds_all[kWavesPerBlock * kWaveLds];
-  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  double* lds = lds_all + wv * kWaveLds;
+  __shared__ double lds[12 * kSSlot];
+  __shared__ uint32_t edge_bits;                 // which edges / corners of the tile moved
+  __shared__ unsigned long long edge_key;        // lowest value that moved on the tile's edge
+  __shared__ uint32_t act[3];                    // waves with work in sweep s at act[s % 3]
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const int qx = (int)(wv >> 1), qy = (int)(wv & 1u);
   const uint32_t n = w.count[round % 3];
   const int px = (int)(lane >> 3), py = (int)(lane & 7u);
   const double INF = __longlong_as_double((long long)kInfBits);
-  const int own_slot = (px + 1) * kRing + (py + 1);
-  unsigned long long wave_min = kInfBits;  // lowest key this wave handed out
+  const int own_slot = (qx * kPps + px + 1) * kSRing + (qy * kPps + py + 1);
+  unsigned long long blk_min = kInfBits;  // lowest key this workgroup handed out (thread 0)
   uint32_t visits = 0, sweeps_total = 0;
 
-  for (uint32_t it = blockIdx.x * kWavesPerBlock + wv; it < n; it += gridDim.x * kWavesPerBlock) {
+  for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
     const uint32_t t = w.list[it];
-    const uint32_t tx = t / g.nty, ty = t - tx * g.nty;
-    const int64_t x0 = (int64_t)tx * kTile, y0 = (int64_t)ty * kTile;
-    double* blk = g.blk + (uint64_t)t * kBlk;
+    const uint32_t tx = t / g.nsy, ty = t - tx * g.nsy;
+    const int64_t X0 = (int64_t)tx * kSTile, Y0 = (int64_t)ty * kSTile;
+    const uint32_t bx = 2 * tx + (uint32_t)qx, by = 2 * ty + (uint32_t)qy;
+    const bool have = bx < g.ntx && by < g.nty;  // the grid may end inside the scheduling tile
+    const uint32_t blk_id = have ? bx * g.nty + by : 0u;
+    double* blk = g.blk + (uint64_t)blk_id * kBlk;
+    if (tid == 0) {
+      edge_bits = 0;
+      edge_key = kInfBits;
+      act[0] = 0;
+      act[1] = 0;
+      act[2] = 0;
+    }
 
     // e[1..4][1..4] = the lane's patch, the rest of e = the cells around it.  floor_[][] is the
     // value a cell may not go below: 0 for a free cell, +inf for a blocked one, its own value for
     // a cell that is only a source.
     double e[6][6], floor_[4][4];
-    const uint32_t m = g.mask[(uint64_t)t * 64 + lane];
+    const uint32_t m = have ? g.mask[(uint64_t)blk_id * 64 + lane] : 0xFFFFu;
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) {
-      const double2 p = *(const double2*)(blk + blk_off(2 * k2, lane));
+      double2 p = make_double2(INF, INF);
+      if (have) p = *(const double2*)(blk + blk_off(2 * k2, lane));
       e[(2 * k2) / 4 + 1][(2 * k2) % 4 + 1] = p.x;
       e[(2 * k2 + 1) / 4 + 1][(2 * k2 + 1) % 4 + 1] = p.y;
     }
@@ -361,141 +385,163 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
         const int k = i * 4 + j;
         const double v = e[i + 1][j + 1];
         floor_[i][j] = ((m >> k) & 1u) ? INF : (((m >> (16 + k)) & 1u) ? v : 0.0);
-        if (on_rim(i, j)) lds[rim_slot(i, j) * kSlot + own_slot] = v;
+        if (on_rim(i, j)) lds[rim_slot(i, j) * kSSlot + own_slot] = v;
       }
     }
-    // the ring of cells just outside the tile
-    if (lane < 34) {
-      const int o = (int)lane - 1, q = (o + 4) >> 2, j = (o + 4) & 3;
-      lds[(4 + j) * kSlot + 0 * kRing + q] = tile_cell_value(g, x0 - 1, y0 + o);            // slot (3, j)
-      lds[j * kSlot + (kRing - 1) * kRing + q] = tile_cell_value(g, x0 + kTile, y0 + o);    // slot (0, j)
+    // the ring of cells just outside the tile: 66 + 66 + 64 + 64 of them
+    for (int r = (int)tid; r < 2 * (kSTile + 2) + 2 * kSTile; r += 256) {
+      if (r < 2 * (kSTile + 2)) {
+        const int side = r >= kSTile + 2, o = (side ? r - (kSTile + 2) : r) - 1;  // o = -1 .. 64
+        const int q = (o + 4) >> 2, j = (o + 4) & 3;
+        if (!side)
+          lds[(4 + j) * kSSlot + 0 * kSRing + q] = tile_cell_value(g, X0 - 1, Y0 + o);                // slot (3, j)
+        else
+          lds[j * kSSlot + (kSRing - 1) * kSRing + q] = tile_cell_value(g, X0 + kSTile, Y0 + o);      // slot (0, j)
+      } else {
+        const int rr = r - 2 * (kSTile + 2);
+        const int side = rr >= kSTile, o = side ? rr - kSTile : rr;  // o = 0 .. 63
+        const int prow = (o >> 2) + 1, i = o & 3;
+        const int s3 = i == 0 ? 3 : (i == 3 ? 7 : 9 + i), s0 = i == 0 ? 0 : (i == 3 ? 4 : 7 + i);
+        if (!side)
+          lds[s3 * kSSlot + prow * kSRing + 0] = tile_cell_value(g, X0 + o, Y0 - 1);                  // slot (i, 3)
+        else
+          lds[s0 * kSSlot + prow * kSRing + (kSRing - 1)] = tile_cell_value(g, X0 + o, Y0 + kSTile);  // slot (i, 0)
+      }
     }
-    if (lane < 32) {
-      const int o = (int)lane, prow = (o >> 2) + 1, i = o & 3;
-      const int s3 = i == 0 ? 3 : (i == 3 ? 7 : 9 + i), s0 = i == 0 ? 0 : (i == 3 ? 4 : 7 + i);
-      lds[s3 * kSlot + prow * kRing + 0] = tile_cell_value(g, x0 + o, y0 - 1);                  // slot (i, 3)
-      lds[s0 * kSlot + prow * kRing + (kRing - 1)] = tile_cell_value(g, x0 + o, y0 + kTile);    // slot (i, 0)
-    }
+    __syncthreads();
 
-    uint32_t sweeps = 0;
+    // A wave sits a sweep out when nothing it reads has changed since its last one: none of its
+    // own lanes moved and no neighbouring wave moved a patch on the shared edge.
+    const unsigned long long facing_x = qx ? 0x00000000000000FFull : 0xFF00000000000000ull;
+    const unsigned long long facing_y = qy ? 0x0101010101010101ull : 0x8080808080808080ull;
+    // One barrier per sweep.  A wave may read a rim its neighbour has already rewritten in the same
+    // sweep: any mix of old and new values is a state the relaxation may pass through (an 8-byte
+    // LDS access is not torn), and the loop only ends after a sweep in which nobody wrote.
+    uint32_t sweeps = 0, todo = 0xFu;
     for (;;) {
-      const double in11 = e[2][2], in12 = e[2][3], in21 = e[3][2], in22 = e[3][3];
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      const bool active = (todo >> wv) & 1u;
+      const uint32_t nxt = (sweeps + 1u) % 3u;
+      if (tid == 0) act[(sweeps + 2u) % 3u] = 0;  // last read before the previous barrier, filled after the next
+      if (active) {
 #pragma unroll
-      for (int ii = 0; ii < 6; ++ii) {
+        for (int ii = 0; ii < 6; ++ii) {
 #pragma unroll
-        for (int jj = 0; jj < 6; ++jj) {
-          if (ii >= 1 && ii <= 4 && jj >= 1 && jj <= 4) continue;
-          const int dx = ii == 0 ? -1 : (ii == 5 ? 1 : 0), dy = jj == 0 ? -1 : (jj == 5 ? 1 : 0);
-          const int si = ii == 0 ? 3 : (ii == 5 ? 0 : ii - 1), sj = jj == 0 ? 3 : (jj == 5 ? 0 : jj - 1);
-          e[ii][jj] = lds[rim_slot(si, sj) * kSlot + own_slot + dx * kRing + dy];
+          for (int jj = 0; jj < 6; ++jj) {
+            if (ii >= 1 && ii <= 4 && jj >= 1 && jj <= 4) continue;
+            const int dx = ii == 0 ? -1 : (ii == 5 ? 1 : 0), dy = jj == 0 ? -1 : (jj == 5 ? 1 : 0);
+            const int si = ii == 0 ? 3 : (ii == 5 ? 0 : ii - 1), sj = jj == 0 ? 3 : (jj == 5 ? 0 : jj - 1);
+            e[ii][jj] = lds[rim_slot(si, sj) * kSSlot + own_slot + dx * kSRing + dy];
+          }
         }
-      }
+        bool moved = false;  // values only ever go down
 #pragma unroll
-      for (int i = 1; i <= 4; ++i) {
+        for (int i = 1; i <= 4; ++i) {
 #pragma unroll
-        for (int j = 1; j <= 4; ++j) {
-          double v = e[i][j];
-          v = pp_min_f64(v, e[i - 1][j - 1] + diag);
-          v = pp_min_f64(v, e[i - 1][j] + 1.0);
-          v = pp_min_f64(v, e[i - 1][j + 1] + diag);
-          v = pp_min_f64(v, e[i][j - 1] + 1.0);
-          e[i][j] = pp_max_f64(v, floor_[i - 1][j - 1]);
+          for (int j = 1; j <= 4; ++j) {
+            double v = e[i][j];
+            v = pp_min_f64(v, e[i - 1][j - 1] + diag);
+            v = pp_min_f64(v, e[i - 1][j] + 1.0);
+            v = pp_min_f64(v, e[i - 1][j + 1] + diag);
+            v = pp_min_f64(v, e[i][j - 1] + 1.0);
+            v = pp_max_f64(v, floor_[i - 1][j - 1]);
+            moved |= v < e[i][j];
+            e[i][j] = v;
+          }
         }
-      }
 #pragma unroll
-      for (int i = 4; i >= 1; --i) {
+        for (int i = 4; i >= 1; --i) {
 #pragma unroll
-        for (int j = 4; j >= 1; --j) {
-          double v = e[i][j];
-          v = pp_min_f64(v, e[i + 1][j + 1] + diag);
-          v = pp_min_f64(v, e[i + 1][j] + 1.0);
-          v = pp_min_f64(v, e[i + 1][j - 1] + diag);
-          v = pp_min_f64(v, e[i][j + 1] + 1.0);
-          e[i][j] = pp_max_f64(v, floor_[i - 1][j - 1]);
+          for (int j = 4; j >= 1; --j) {
+            double v = e[i][j];
+            v = pp_min_f64(v, e[i + 1][j + 1] + diag);
+            v = pp_min_f64(v, e[i + 1][j] + 1.0);
+            v = pp_min_f64(v, e[i + 1][j - 1] + diag);
+            v = pp_min_f64(v, e[i][j + 1] + 1.0);
+            v = pp_max_f64(v, floor_[i - 1][j - 1]);
+            moved |= v < e[i][j];
+            e[i][j] = v;
+          }
         }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      bool moved = __double_as_longlong(in11) != __double_as_longlong(e[2][2]) ||
-                   __double_as_longlong(in12) != __double_as_longlong(e[2][3]) ||
-                   __double_as_longlong(in21) != __double_as_longlong(e[3][2]) ||
-                   __double_as_longlong(in22) != __double_as_longlong(e[3][3]);
+        if (moved) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (!on_rim(i, j)) continue;
-          double* slot = &lds[rim_slot(i, j) * kSlot + own_slot];
-          const double v = e[i + 1][j + 1];
-          moved |= __double_as_longlong(*slot) != __double_as_longlong(v);
-          *slot = v;
+            for (int j = 0; j < 4; ++j)
+              if (on_rim(i, j)) lds[rim_slot(i, j) * kSSlot + own_slot] = e[i + 1][j + 1];
+          }
+        }
+        const unsigned long long bal = __ballot(moved);
+        if (bal != 0ull && lane == 0) {
+          uint32_t hit = 1u << wv;
+          if (bal & facing_x) hit |= 1u << (wv ^ 2u);
+          if (bal & facing_y) hit |= 1u << (wv ^ 1u);
+          if (bal & facing_x & facing_y) hit |= 1u << (wv ^ 3u);
+          atomicOr(&act[nxt], hit);
         }
       }
       ++sweeps;
-      if (__ballot(moved) == 0ull) break;
+      __syncthreads();  // rims and the activity word are published
+      todo = act[nxt];
+      if (todo == 0) break;
     }
 
     // write back what moved; cells on the tile's edge wake the neighbours that read them
-    bool m_xlo = false, m_xhi = false, m_ylo = false, m_yhi = false;
-    bool c00 = false, c01 = false, c10 = false, c11 = false, first_col = false, last_col = false;
-    double edge_min = INF;  // lowest value that moved on the tile's edge
+    uint32_t bits = 0;  // 0 x-lo, 1 x-hi, 2 y-lo, 3 y-hi, 4..7 corners (00, 01, 10, 11), 8 first col, 9 last col
+    double edge_min = INF;
+    if (have) {
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) {
-      double2* p = (double2*)(blk + blk_off(2 * k2, lane));
-      const double2 old = *p;
-      bool any = false;
+      for (int k2 = 0; k2 < 8; ++k2) {
+        double2* p = (double2*)(blk + blk_off(2 * k2, lane));
+        const double2 old = *p;
+        bool any = false;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int k = 2 * k2 + h, i = k / 4, j = k % 4;
-        const double v = e[i + 1][j + 1];
-        if (__double_as_longlong(h ? old.y : old.x) != __double_as_longlong(v)) {
-          any = true;
-          const int li = 4 * px + i, lj = 4 * py + j;
-          if (li == 0 || li == kTile - 1 || lj == 0 || lj == kTile - 1) edge_min = pp_min_f64(edge_min, v);
-          m_xlo |= li == 0;
-          m_xhi |= li == kTile - 1;
-          m_ylo |= lj == 0;
-          m_yhi |= lj == kTile - 1;
-          c00 |= li == 0 && lj == 0;
-          c01 |= li == 0 && lj == kTile - 1;
-          c10 |= li == kTile - 1 && lj == 0;
-          c11 |= li == kTile - 1 && lj == kTile - 1;
-          first_col |= (uint64_t)(x0 + li) == w.own_first;
-          last_col |= (uint64_t)(x0 + li) == w.own_last;
+        for (int h = 0; h < 2; ++h) {
+          const int k = 2 * k2 + h, i = k / 4, j = k % 4;
+          const double v = e[i + 1][j + 1];
+          if (__double_as_longlong(h ? old.y : old.x) != __double_as_longlong(v)) {
+            any = true;
+            const int li = qx * kTile + 4 * px + i, lj = qy * kTile + 4 * py + j;
+            const bool xl = li == 0, xh = li == kSTile - 1, yl = lj == 0, yh = lj == kSTile - 1;
+            if (xl || xh || yl || yh) edge_min = pp_min_f64(edge_min, v);
+            bits |= (xl ? 1u : 0u) | (xh ? 2u : 0u) | (yl ? 4u : 0u) | (yh ? 8u : 0u);
+            bits |= (xl && yl ? 16u : 0u) | (xl && yh ? 32u : 0u) | (xh && yl ? 64u : 0u) | (xh && yh ? 128u : 0u);
+            bits |= ((uint64_t)(X0 + li) == w.own_first ? 256u : 0u) | ((uint64_t)(X0 + li) == w.own_last ? 512u : 0u);
+          }
         }
+        if (any) *p = make_double2(e[(2 * k2) / 4 + 1][(2 * k2) % 4 + 1], e[(2 * k2 + 1) / 4 + 1][(2 * k2 + 1) % 4 + 1]);
       }
-      if (any) *p = make_double2(e[(2 * k2) / 4 + 1][(2 * k2) % 4 + 1], e[(2 * k2 + 1) / 4 + 1][(2 * k2 + 1) % 4 + 1]);
     }
-    const bool b_xlo = __ballot(m_xlo) != 0ull, b_xhi = __ballot(m_xhi) != 0ull;
-    const bool b_ylo = __ballot(m_ylo) != 0ull, b_yhi = __ballot(m_yhi) != 0ull;
-    const bool b00 = __ballot(c00) != 0ull, b01 = __ballot(c01) != 0ull;
-    const bool b10 = __ballot(c10) != 0ull, b11 = __ballot(c11) != 0ull;
-    const bool b_first = __ballot(first_col) != 0ull, b_last = __ballot(last_col) != 0ull;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) edge_min = pp_min_f64(edge_min, __shfl_xor(edge_min, off));
-    const unsigned long long ek = (unsigned long long)__double_as_longlong(edge_min);
-    if (b_xlo || b_xhi || b_ylo || b_yhi) wave_min = min(wave_min, ek);
-    // lanes 0..7 wake one neighbour each
-    if (lane < 8) {
-      const int ddx = lane < 3 ? -1 : (lane < 5 ? 0 : 1);
-      const int ddy = (lane == 0 || lane == 3 || lane == 5) ? -1 : ((lane == 2 || lane == 4 || lane == 7) ? 1 : 0);
-      const bool wake = lane == 0 ? b00 : lane == 1 ? b_xlo : lane == 2 ? b01 : lane == 3 ? b_ylo
-                      : lane == 4 ? b_yhi : lane == 5 ? b10 : lane == 6 ? b_xhi : b11;
-      if (wake) tile_wake(g, w, (int64_t)tx + ddx, (int64_t)ty + ddy, ek);
+    for (int off = 32; off >= 1; off >>= 1) {
+      bits |= __shfl_xor(bits, off);
+      edge_min = pp_min_f64(edge_min, __shfl_xor(edge_min, off));
     }
-    if (lane == 0) {
-      if (b_first) w.status[2] = 1;
-      if (b_last) w.status[3] = 1;
+    if (lane == 0 && bits) {
+      atomicOr(&edge_bits, bits);
+      atomicMin(&edge_key, (unsigned long long)__double_as_longlong(edge_min));
     }
-    ++visits;
-    sweeps_total += sweeps;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    const uint32_t eb = edge_bits;
+    const unsigned long long ek = edge_key;
+    // threads 0..7 wake one neighbour each
+    if (tid < 8) {
+      const int ddx = tid < 3 ? -1 : (tid < 5 ? 0 : 1);
+      const int ddy = (tid == 0 || tid == 3 || tid == 5) ? -1 : ((tid == 2 || tid == 4 || tid == 7) ? 1 : 0);
+      const uint32_t need = tid == 0 ? 16u : tid == 1 ? 1u : tid == 2 ? 32u : tid == 3 ? 4u
+                          : tid == 4 ? 8u : tid == 5 ? 64u : tid == 6 ? 2u : 128u;
+      if (eb & need) tile_wake(g, w, (int64_t)tx + ddx, (int64_t)ty + ddy, ek);
+    }
+    if (tid == 0) {
+      if (eb & 15u) blk_min = min(blk_min, ek);
+      if (eb & 256u) w.status[2] = 1;
+      if (eb & 512u) w.status[3] = 1;
+      ++visits;
+      sweeps_total += sweeps;
+    }
+    __syncthreads();  // edge_bits / edge_key and the LDS rims are reused by the next tile
   }
-  if (lane == 0 && visits) {
-    if (wave_min != kInfBits) atomicMin(&w.minkey[(round + 1) % 3], wave_min);
+  if (tid == 0 && visits) {
+    if (blk_min != kInfBits) atomicMin(&w.minkey[(round + 1) % 3], blk_min);
     atomicAdd(&w.status[0], visits);
     atomicAdd(&w.status[1], sweeps_total);
   }
@@ -512,7 +558,7 @@ __global__ void k_seed_goal(TileGrid g, TileWork w, int64_t x, int64_t y) {
   const uint32_t t = (uint32_t)(x >> 5) * g.nty + (uint32_t)(y >> 5);
   const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
   g.blk[(uint64_t)t * kBlk + blk_off((lx & 3u) * 4u + (ly & 3u), (lx >> 2) * 8u + (ly >> 2))] = 0.0;
-  tile_wake(g, w, x >> 5, y >> 5, 0ull);
+  tile_wake(g, w, x >> 6, y >> 6, 0ull);
   atomicMin(&w.minkey[0], 0ull);
 }
 
@@ -524,7 +570,7 @@ __global__ void k_seed_goals(TileGrid g, TileWork w, uint32_t planes, uint64_t p
   const uint32_t t = (uint32_t)(x >> 5) * g.nty + (uint32_t)(y >> 5);
   const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
   g.blk[(uint64_t)t * kBlk + blk_off((lx & 3u) * 4u + (ly & 3u), (lx >> 2) * 8u + (ly >> 2))] = 0.0;
-  tile_wake(g, w, x >> 5, y >> 5, 0ull);
+  tile_wake(g, w, x >> 6, y >> 6, 0ull);
   if (p == 0) atomicMin(&w.minkey[0], 0ull);
 }
 
@@ -546,7 +592,7 @@ __global__ void k_take_halo(DenseView d, TileGrid g, TileWork w, const double* _
       for (int dx = -1; dx <= 1; ++dx)
         for (int dy = -1; dy <= 1; ++dy) {
           const int64_t nx = (int64_t)col + dx, ny = (int64_t)y + dy;
-          if (nx >= 0 && ny >= 0) tile_wake(g, w, nx >> 5, ny >> 5, kb);
+          if (nx >= 0 && ny >= 0) tile_wake(g, w, nx >> 6, ny >> 6, kb);
         }
       atomicMin(&w.minkey[0], kb);
     }
@@ -556,16 +602,18 @@ __global__ void k_take_halo(DenseView d, TileGrid g, TileWork w, const double* _
 struct TileRun {
   TileGrid g{};
   TileWork w{};
+  uint32_t nblocks = 0;  // 32x32 blocks (pack / unpack work items)
 };
 
 // Blocked costs, masks and work lists live in a context-owned buffer (grown on demand) so
 // repeated calls do not allocate.
 int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run) {
   const uint64_t ntx = (d.ncols + kTile - 1) / kTile, nty = (d.yw + kTile - 1) / kTile;
-  const uint64_t ntiles = ntx * nty;
-  if (ntiles == 0 || ntiles >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
+  const uint64_t nblocks = ntx * nty;
+  const uint64_t nsx = (ntx + 1) / 2, nsy = (nty + 1) / 2, ntiles = nsx * nsy;  // scheduling tiles
+  if (nblocks == 0 || nblocks >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  const size_t b_blk = al(ntiles * kBlk * 8), b_mask = al(ntiles * 64 * 4), b_list = al(ntiles * 4);
+  const size_t b_blk = al(nblocks * kBlk * 8), b_mask = al(nblocks * 64 * 4), b_list = al(ntiles * 4);
   const size_t b_bits = al(((ntiles + 63) / 64) * 8), b_key = al(ntiles * 8), b_misc = 256;
   const size_t need = b_blk + b_mask + b_list + b_bits + b_key + b_misc;
   if (need > ctx->wave_bytes) {
@@ -582,6 +630,9 @@ int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run) {
   b += b_mask;
   run->g.ntx = (uint32_t)ntx;
   run->g.nty = (uint32_t)nty;
+  run->g.nsx = (uint32_t)nsx;
+  run->g.nsy = (uint32_t)nsy;
+  run->nblocks = (uint32_t)nblocks;
   run->w.list = (uint32_t*)b;
   b += b_list;
   run->w.bitmap = (uint32_t*)b;
@@ -608,8 +659,7 @@ int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run) {
 // round over an empty list costs two empty launches.
 int32_t tile_run(pp_ctx* ctx, TileRun& run, uint64_t* rounds_out, uint32_t status_out[4]) {
   const double diag = std::hypot(1.0, 1.0);  // u_cost((+-1, +-1)), astar.rs:213-215
-  const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus * 4,
-                                                     (run.w.ntiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus * 4, run.w.ntiles);
   const unsigned lgrid = (run.w.ntiles + 255) / 256;
   uint32_t round = 0;
   uint32_t counts[3];
@@ -617,8 +667,7 @@ int32_t tile_run(pp_ctx* ctx, TileRun& run, uint64_t* rounds_out, uint32_t statu
   for (;;) {
     for (uint32_t j = 0; j < batch; ++j, ++round) {
       hipLaunchKernelGGL(k_tile_list, dim3(lgrid), dim3(256), 0, ctx->stream, run.g, run.w, round);
-      hipLaunchKernelGGL(k_tile_round, dim3(grid), dim3(64 * kWavesPerBlock), 0, ctx->stream, run.g,
-                         run.w, round, diag);
+      hipLaunchKernelGGL(k_tile_round, dim3(grid), dim3(256), 0, ctx->stream, run.g, run.w, round, diag);
     }
     PP_HIP(ctx, hipGetLastError());
     PP_HIP(ctx, hipMemcpyAsync(counts, run.w.count, 12, hipMemcpyDeviceToHost, ctx->stream));
@@ -663,14 +712,14 @@ extern "C" int32_t pp_wavefront_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const
   TileRun run;
   int32_t st = tile_prepare(ctx, d, &run);
   if (st != PP_OK) return st;
-  const unsigned sg = tile_stream_grid(ctx, run.w.ntiles);
-  hipLaunchKernelGGL(k_tile_pack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.w.ntiles, 1);
+  const unsigned sg = tile_stream_grid(ctx, run.nblocks);
+  hipLaunchKernelGGL(k_tile_pack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks, 1);
   hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, run.g, run.w, (int64_t)goal_x,
                      (int64_t)goal_y);
   uint32_t status[4];
   st = tile_run(ctx, run, iters, status);
   if (st != PP_OK) return st;
-  hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.w.ntiles);
+  hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks);
   PP_HIP(ctx, hipGetLastError());
   return PP_OK;
 }
@@ -706,14 +755,14 @@ int32_t pp_wavefront_multi_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint
     TileRun run;
     st = tile_prepare(ctx, d, &run);
     if (st != PP_OK) return st;
-    const unsigned sg = tile_stream_grid(ctx, run.w.ntiles);
-    hipLaunchKernelGGL(k_tile_pack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.w.ntiles, 1);
+    const unsigned sg = tile_stream_grid(ctx, run.nblocks);
+    hipLaunchKernelGGL(k_tile_pack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks, 1);
     hipLaunchKernelGGL(k_seed_goals, dim3((np + 63) / 64), dim3(64), 0, ctx->stream, run.g, run.w, np,
                        xw + 1, (const int64_t*)d_goals);
     uint32_t status[4];
     st = tile_run(ctx, run, nullptr, status);
     if (st != PP_OK) return st;
-    hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.w.ntiles);
+    hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks);
     PP_HIP(ctx, hipGetLastError());
     PP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // d_goals is reused by the next pass
   }
@@ -742,14 +791,14 @@ extern "C" int32_t pp_wavefront_slab_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, 
   if (d_halo_lo_new || d_halo_hi_new)
     hipLaunchKernelGGL(k_take_halo, dim3((unsigned)((yw + 255) / 256)), dim3(256), 0, ctx->stream, d,
                        run.g, run.w, d_halo_lo_new, d_halo_hi_new);
-  const unsigned sg = tile_stream_grid(ctx, run.w.ntiles);
-  hipLaunchKernelGGL(k_tile_pack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.w.ntiles, 0);
+  const unsigned sg = tile_stream_grid(ctx, run.nblocks);
+  hipLaunchKernelGGL(k_tile_pack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks, 0);
   if (seed_goal && goal_owned)
     hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, run.g, run.w, d.goal_x, d.goal_y);
   uint32_t status[4] = {0, 0, 0, 0};
   st = tile_run(ctx, run, iters, status);
   if (st != PP_OK) return st;
-  hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.w.ntiles);
+  hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks);
   PP_HIP(ctx, hipGetLastError());
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (changed_lo) *changed_lo = (int32_t)status[2];

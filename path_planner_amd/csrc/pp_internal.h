@@ -70,7 +70,7 @@ struct pp_ctx {
   // work lists of the heuristic relaxation (grown on demand, never shrunk)
   void* wave_buf = nullptr;
   size_t wave_bytes = 0;
-  double wave_band = 64.0;  // cost band of tiles relaxed in one round
+  double wave_band = 128.0;  // cost band of tiles relaxed in one round
   uint64_t wave_stats[4] = {0, 0, 0, 0};  // last relaxation: rounds, tile visits, sweep pairs, tiles
   void* pinned = nullptr;
   size_t pinned_bytes = 0;

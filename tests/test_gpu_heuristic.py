@@ -202,7 +202,7 @@ def test_relax_band_does_not_change_the_result(ctx):
         api.wavefront_dev(ctx, d_obs, gx, gy, cost)
         ctx.synchronize()
         outs.append(cost.cpu().numpy())
-    assert ctx.lib.pp_ctx_set_relax_band(ctx.h, 64.0) == 0
+    assert ctx.lib.pp_ctx_set_relax_band(ctx.h, 128.0) == 0
     st, exp = O.wavefront(obs, gx, gy)
     for o in outs:
         assert (o.view(np.uint64) == exp.view(np.uint64)).all()

@@ -22,6 +22,10 @@ template <int OP> __global__ void __launch_bounds__(256) k(float* out, int iters
       if (OP == 7) f[i] = __builtin_fmaxf(__builtin_fmaxf(f[i], a), b);  // max3
       if (OP == 8) u[i] = (unsigned)(f[i] = f[i] + a);    // add + cvt_u32
       if (OP == 9) d[i] = __builtin_floor(d[i] * (double)a);  // f64 mul + floor
+      if (OP == 10) asm volatile("v_min_f64 %0, %1, %2" : "=v"(d[i]) : "v"(d[i]), "v"(d[(i + 1) & 7]));
+      if (OP == 11) { unsigned long long x = __double_as_longlong(d[i]), y = __double_as_longlong(d[(i + 1) & 7]); d[i] = __longlong_as_double(x < y ? x : y); }
+      if (OP == 12) d[i] = d[i] < d[(i + 1) & 7] ? d[i] : d[(i + 1) & 7];
+      if (OP == 13) asm volatile("v_max_f64 %0, %1, %2" : "=v"(d[i]) : "v"(d[i]), "v"(d[(i + 1) & 7]));
     }
   }
   float s = 0; for (int i = 0; i < 8; ++i) s += f[i] + (float)d[i] + (float)u[i] + p[i].x + p[i].y;
@@ -51,5 +55,9 @@ int main() {
   run(k<7>, "v_max3_f32", 8);
   run(k<8>, "add_f32 + cvt_u32_f32", 16);
   run(k<9>, "mul_f64 + floor_f64", 16);
+  run(k<10>, "v_min_f64", 8);
+  run(k<11>, "u64 cmp + 2 cndmask", 8);
+  run(k<12>, "f64 cmp + 2 cndmask", 8);
+  run(k<13>, "v_max_f64", 8);
   return 0;
 }

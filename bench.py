@@ -203,7 +203,7 @@ def main():
         wl = {"workload": f"holonomic heuristic wavefront, {ncell}x{ncell} grid (border + "
                           "Bernoulli 0.2), goal at centre", "cells": ncell * ncell,
               "parallelism": f"x-slabs x{world}, halo-column exchange" if world > 1 else "1 GPU"}
-        dtype, kernel = "f64", "k_wave_*"
+        dtype, kernel = "f64", "k_tile_round+k_tile_list"
         if world == 1:
             obs = torch.from_numpy(obs_np).to(dev)
             cost = torch.empty((ncell, ncell), dtype=torch.float64, device=dev)

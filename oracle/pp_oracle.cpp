@@ -945,6 +945,102 @@ int32_t orc_wavefront(uint64_t xw, uint64_t yw, const uint8_t* obs, uint64_t goa
   return dijkstra(g, o, goal_x, goal_y, cost);
 }
 
+// ------------------------------------------------------------------ plain grid A* (astar.rs:53-132)
+namespace {
+struct GridNode {  // HolonomicNode, astar.rs:9-15
+  uint64_t x, y;
+  double cost;
+  int64_t pind;
+};
+}  // namespace
+
+int32_t orc_astar(const double* ox, const double* oy, uint64_t n, double sx, double sy, double gx,
+                  double gy, double reso, double rr, double* path_x, double* path_y, uint64_t cap,
+                  uint64_t* len, uint64_t* closed_order, uint64_t closed_cap, uint64_t* expansions) {
+  if (n == 0) return PP_ERR_EMPTY_MAP;
+  *len = 0;
+  const GridNode n_start{sat_usize(std::round(sx / reso)), sat_usize(std::round(sy / reso)), 0.0, -1};
+  const GridNode n_goal{sat_usize(std::round(gx / reso)), sat_usize(std::round(gy / reso)), 0.0, -1};
+  std::vector<double> oxf(n), oyf(n);
+  for (uint64_t i = 0; i < n; ++i) {  // :77-78
+    oxf[i] = ox[i] / reso;
+    oyf[i] = oy[i] / reso;
+  }
+  const GridDims g = grid_dims(oxf, oyf);  // calc_parameters :232-242
+  std::vector<uint8_t> obs;
+  calc_obsmap(oxf, oyf, rr, reso, g, obs, 1);
+  auto calc_index = [&](const GridNode& nd) { return (nd.y - g.miny) * g.xw + (nd.x - g.minx); };  // :228-230
+  auto fvalue = [&](const GridNode& nd) {  // :217-226
+    return nd.cost + std::hypot((double)nd.x - (double)n_goal.x, (double)nd.y - (double)n_goal.y);
+  };
+  static const int mdx[8] = {-1, -1, 0, 1, 1, 1, 0, -1};  // :297-308
+  static const int mdy[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+
+  const uint64_t goal_ind = calc_index(n_goal);
+  std::unordered_map<uint64_t, GridNode> open_set, closed_set;
+  open_set.emplace(calc_index(n_start), n_start);
+  // (Reverse(f), ind) in a max-heap: lowest f first, ties to the larger ind (HeapLess)
+  std::priority_queue<HeapEnt, std::vector<HeapEnt>, HeapLess> q;
+  q.push({fvalue(n_start), calc_index(n_start)});
+  uint64_t n_closed = 0;
+  bool found = false;
+  while (!open_set.empty()) {  // :93
+    const uint64_t ind = q.top().ind;
+    q.pop();
+    const GridNode cur = open_set.at(ind);
+    open_set.erase(ind);
+    closed_set[ind] = cur;
+    if (closed_order && n_closed < closed_cap) closed_order[n_closed] = ind;
+    ++n_closed;
+    if (goal_ind == ind) {
+      found = true;
+      break;
+    }
+    for (int k = 0; k < 8; ++k) {
+      GridNode nd{(uint64_t)((int64_t)cur.x + mdx[k]), (uint64_t)((int64_t)cur.y + mdy[k]),
+                  cur.cost + std::hypot((double)mdx[k], (double)mdy[k]), (int64_t)ind};
+      // check_node :200-211
+      if (nd.x <= g.minx || nd.x >= g.maxx || nd.y <= g.miny || nd.y >= g.maxy) continue;
+      if (obs[(nd.x - g.minx) * g.yw + (nd.y - g.miny)]) continue;
+      const uint64_t n_ind = calc_index(nd);
+      if (closed_set.count(n_ind)) continue;
+      auto it = open_set.find(n_ind);
+      if (it != open_set.end()) {
+        if (it->second.cost > nd.cost) {
+          it->second.cost = nd.cost;
+          it->second.pind = (int64_t)ind;
+        }
+      } else {
+        open_set.emplace(n_ind, nd);
+        q.push({fvalue(nd), n_ind});
+      }
+    }
+  }
+  if (expansions) *expansions = n_closed;
+  if (!found) return PP_NO_PATH;
+  // extract_path :263-295
+  std::vector<double> px{(double)n_goal.x}, py{(double)n_goal.y};
+  uint64_t n_ind = goal_ind;
+  for (;;) {
+    auto it = closed_set.find(n_ind);
+    if (it == closed_set.end()) break;
+    const GridNode& nd = it->second;
+    px.push_back((double)nd.x);
+    py.push_back((double)nd.y);
+    n_ind = (uint64_t)nd.pind;
+    if (nd.x == n_start.x && nd.y == n_start.y && nd.cost == n_start.cost && nd.pind == n_start.pind) break;
+  }
+  std::reverse(px.begin(), px.end());
+  std::reverse(py.begin(), py.end());
+  *len = px.size();
+  if (px.size() > cap) return PP_ERR_CAPACITY;
+  for (size_t i = 0; i < px.size(); ++i) {
+    path_x[i] = px[i] * reso;
+    path_y[i] = py[i] * reso;
+  }
+  return PP_OK;
+}
+
 // ------------------------------------------------------------------ Reeds-Shepp ABI
 int32_t orc_rs_words(double sx, double sy, double syaw, double gx, double gy, double gyaw,
                      double maxc, int32_t* n_paths, pp_rs_word* words) {

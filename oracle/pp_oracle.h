@@ -64,6 +64,12 @@ int32_t orc_obsmap(const double *ox, const double *oy, uint64_t n, double reso, 
 /* src/astar.rs:134-198 */
 int32_t orc_heuristic(const double *ox, const double *oy, uint64_t n, double gx, double gy,
                       double reso, double rr, double *hmap, uint64_t cap, uint64_t dims[6]);
+/* src/astar.rs:53-132 + extract_path :263-295 (rec = None).  closed_order: calc_index keys in
+ * the order nodes are closed.  Parity of the tie rule is unpinned: the reference holds no output of
+ * this planner, and the Python twin's open list (heapdict) breaks ties differently. */
+int32_t orc_astar(const double *ox, const double *oy, uint64_t n, double sx, double sy, double gx,
+                  double gy, double reso, double rr, double *path_x, double *path_y, uint64_t cap,
+                  uint64_t *len, uint64_t *closed_order, uint64_t closed_cap, uint64_t *expansions);
 /* src/astar.rs:153-198 on a given raster (minx=miny=0, maxx=xw, maxy=yw). */
 int32_t orc_wavefront(uint64_t xw, uint64_t yw, const uint8_t *obs, uint64_t goal_x,
                       uint64_t goal_y, double *cost);

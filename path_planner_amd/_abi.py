@@ -168,6 +168,10 @@ def load_library(path=None):
         "pp_plan": (C.c_int32, [vp, vp, cfg, d, d, C.POINTER(Path), C.POINTER(PlanStats)]),
         "pp_plan_batch": (C.c_int32, [vp, vp, cfg, C.c_uint64, d, d, C.POINTER(Path),
                                       C.POINTER(PlanStats), i32]),
+        "pp_astar_plan": (C.c_int32, [vp, vp] + [C.c_double] * 6 + [d, d, C.c_uint64, u64, u64,
+                                                                    C.c_uint64, u64]),
+        "pp_astar_plan_batch": (C.c_int32, [vp, vp, C.c_uint64, d, d, C.c_double, C.c_double, d, d,
+                                            C.c_uint64, u64, i32, u64]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

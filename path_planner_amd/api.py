@@ -338,5 +338,56 @@ def plan_batch(ctx, omap, conf, starts, goals, cap=4096, closed_cap=0):
             "stats": stats, "closed": closed}
 
 
+def astar_planning(ctx, omap, sx, sy, gx, gy, reso, rr, cap=0, closed_cap=0):
+    """astar.rs:53-132 (rec = None): (pathx, pathy) or None; with closed_cap > 0 also the
+    calc_index keys in closing order."""
+    if cap == 0:  # size the path first; a query without a path is already answered by this call
+        closed = np.zeros(closed_cap, np.uint64)
+        n, ex = C.c_uint64(0), C.c_uint64(0)
+        st = ctx.lib.pp_astar_plan(ctx.h, omap.h, sx, sy, gx, gy, reso, rr, None, None, 0,
+                                   C.byref(n), _p(closed, C.c_uint64) if closed_cap else None,
+                                   closed_cap, C.byref(ex))
+        if st == A.PP_NO_PATH:
+            return None if closed_cap == 0 else (None, closed[: min(ex.value, closed_cap)].copy())
+        _chk(st, "pp_astar_plan", (A.PP_ERR_CAPACITY,))
+        cap = n.value
+    px, py = np.zeros(cap), np.zeros(cap)
+    closed = np.zeros(closed_cap, np.uint64)
+    n, ex = C.c_uint64(0), C.c_uint64(0)
+    st = ctx.lib.pp_astar_plan(ctx.h, omap.h, sx, sy, gx, gy, reso, rr, _p(px), _p(py), cap,
+                               C.byref(n), _p(closed, C.c_uint64) if closed_cap else None,
+                               closed_cap, C.byref(ex))
+    order = closed[: min(ex.value, closed_cap)].copy()
+    if st == A.PP_NO_PATH:
+        return None if closed_cap == 0 else (None, order)
+    _chk(st, "pp_astar_plan")
+    path = (px[: n.value].copy(), py[: n.value].copy())
+    return path if closed_cap == 0 else (path, order)
+
+
+def astar_planning_batch(ctx, omap, starts, goals, reso, rr, cap=0):
+    """n queries {x, y} against one raster: list of (pathx, pathy) or None, and expansions."""
+    starts, goals = _f64(starts).reshape(-1, 2), _f64(goals).reshape(-1, 2)
+    n = len(starts)
+    off = np.zeros(n + 1, np.uint64)
+    status = np.zeros(n, np.int32)
+    ex = np.zeros(n, np.uint64)
+    if cap == 0:
+        st = ctx.lib.pp_astar_plan_batch(ctx.h, omap.h, n, _p(starts), _p(goals), reso, rr, None,
+                                         None, 0, _p(off, C.c_uint64), _p(status, C.c_int32),
+                                         _p(ex, C.c_uint64))
+        _chk(st, "pp_astar_plan_batch", (A.PP_OK, A.PP_ERR_CAPACITY))
+        cap = max(1, int(off[n]))
+    px, py = np.zeros(cap), np.zeros(cap)
+    _chk(ctx.lib.pp_astar_plan_batch(ctx.h, omap.h, n, _p(starts), _p(goals), reso, rr, _p(px),
+                                     _p(py), cap, _p(off, C.c_uint64), _p(status, C.c_int32),
+                                     _p(ex, C.c_uint64)), "pp_astar_plan_batch")
+    out = []
+    for i in range(n):
+        a, b = int(off[i]), int(off[i + 1])
+        out.append((px[a:b].copy(), py[a:b].copy()) if status[i] == A.PP_OK else None)
+    return out, ex
+
+
 def demo_maxc(conf):
     return math.tan(conf.max_steer) / conf.car.wheel_base

@@ -58,6 +58,8 @@ def lib():
         "orc_analytic_batch": (C.c_int32, [vp, cfg, C.c_uint64, d, d, d, d, d, d, u8, i32, i32, W, d]),
         "orc_plan": (C.c_int32, [vp, cfg, d, d, C.POINTER(A.Path), C.POINTER(A.PlanStats)]),
         "orc_set_max_expansions": (None, [C.c_uint64]),
+        "orc_astar": (C.c_int32, [d, d, C.c_uint64] + [C.c_double] * 6 + [d, d, C.c_uint64, u64, u64,
+                                                                           C.c_uint64, u64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -195,6 +197,20 @@ def heuristic(ox, oy, gx, gy, reso, rr):
     st = lib().orc_heuristic(_p(ox), _p(oy), len(ox), gx, gy, reso, rr, _p(out), len(out),
                              _p(dims, C.c_uint64))
     return st, out.reshape(int(dims[4]), int(dims[5])), dims
+
+
+def astar(ox, oy, sx, sy, gx, gy, reso, rr, cap=100000, closed_cap=1000000):
+    """(status, (pathx, pathy) or None, closing order)."""
+    ox, oy = _f64(ox), _f64(oy)
+    px, py = np.zeros(cap), np.zeros(cap)
+    closed = np.zeros(closed_cap, np.uint64)
+    n, ex = C.c_uint64(0), C.c_uint64(0)
+    st = lib().orc_astar(_p(ox), _p(oy), len(ox), sx, sy, gx, gy, reso, rr, _p(px), _p(py), cap,
+                         C.byref(n), _p(closed, C.c_uint64), closed_cap, C.byref(ex))
+    order = closed[: min(ex.value, closed_cap)].copy()
+    if st != 0:
+        return st, None, order
+    return st, (px[: n.value].copy(), py[: n.value].copy()), order
 
 
 def wavefront(obs, goal_x, goal_y):

@@ -317,23 +317,27 @@ def plan_batch(ctx, omap, conf, starts, goals, cap=4096, closed_cap=0):
     X, Y, YAW = np.zeros((n, cap)), np.zeros((n, cap)), np.zeros((n, cap))
     D = np.zeros((n, cap), np.int64)
     closed = np.zeros((n, max(closed_cap, 1)), np.uint64)
-    paths = (A.Path * n)()
+    # the pp_path array is filled as a structured numpy array (one vector operation per field)
+    pt = np.zeros(n, dtype=[("x", "u8"), ("y", "u8"), ("yaw", "u8"), ("direction", "u8"), ("cap", "u8"),
+                            ("len", "u8"), ("cost", "f8")])
+    assert pt.itemsize == C.sizeof(A.Path)
+    row = np.arange(n, dtype=np.uint64) * np.uint64(cap * 8)
+    for name, arr in (("x", X), ("y", Y), ("yaw", YAW), ("direction", D)):
+        pt[name] = np.uint64(arr.ctypes.data) + row
+    pt["cap"] = cap
+    paths = C.cast(pt.ctypes.data, C.POINTER(A.Path))
     stats = (A.PlanStats * n)()
-    dp, ip, up = A.c_double_p, A.c_i64_p, A.c_u64_p
-    xs, ys, ws, ds, cs = (a.ctypes.data for a in (X, Y, YAW, D, closed))
-    for i in range(n):
-        o = i * cap * 8
-        paths[i] = A.Path(C.cast(xs + o, dp), C.cast(ys + o, dp), C.cast(ws + o, dp),
-                          C.cast(ds + o, ip), cap, 0, 0.0)
-        if closed_cap:
+    if closed_cap:
+        cs, up = closed.ctypes.data, A.c_u64_p
+        for i in range(n):
             stats[i].closed_cap = closed_cap
             stats[i].closed_order = C.cast(cs + i * closed_cap * 8, up)
     status = np.zeros(n, np.int32)
     st = ctx.lib.pp_plan_batch(ctx.h, omap.h, C.byref(conf), n, _p(starts), _p(goals), paths, stats,
                                _p(status, C.c_int32))
     _chk(st, "pp_plan_batch")
-    lens = np.array([paths[i].len for i in range(n)], np.int64)
-    cost = np.array([paths[i].cost for i in range(n)])
+    lens = pt["len"].astype(np.int64)
+    cost = pt["cost"].copy()
     return {"status": status, "x": X, "y": Y, "yaw": YAW, "dir": D, "len": lens, "cost": cost,
             "stats": stats, "closed": closed}
 

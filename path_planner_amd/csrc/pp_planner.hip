@@ -60,15 +60,39 @@ struct HeapLess {  // BinaryHeap<(Reverse(f), key)>: top = min f, ties -> larges
   }
 };
 
+// What the device returns for one node: the analytic shot from its end pose and its P primitive
+// rollouts.  It is a function of the node alone, so it can be fetched before the node is closed.
+struct Expansion {
+  PpShotOut shot;
+  std::vector<uint8_t> valid;   // P
+  std::vector<uint64_t> words;  // 8 x P: xind, yind, yawind, cost, end x, end y, end yaw, f (as bits)
+};
+// The same data in place, in the round's staging buffer or in a cache entry.
+struct ExpansionView {
+  const PpShotOut* shot;
+  const uint8_t* valid;
+  const uint64_t* xind;
+  const uint64_t* yind;
+  const int64_t* yawind;
+  const double* cost;
+  const double* ex;
+  const double* ey;
+  const double* eyaw;
+  const double* f;
+};
+
 struct Query {
   double start[3], goal[3];
   int32_t hmap_slot = -1;
   std::vector<SNode> nodes;
   std::unordered_map<uint64_t, int32_t> open, closed;
-  std::priority_queue<HeapEnt, std::vector<HeapEnt>, HeapLess> heap;
+  std::vector<HeapEnt> heap;  // std::push_heap / pop_heap under HeapLess
+  std::unordered_map<int32_t, Expansion> cache;  // expansions fetched ahead of their node's turn
+  std::vector<int32_t> want;                     // nodes to expand in this round, want[0] = curr
+  size_t item0 = 0;                              // this query's first item in the round's batch
   int32_t status = PP_OK;
   bool live = false;
-  int32_t curr = -1;       // node closed in this round
+  int32_t curr = -1;       // node closed last and not yet expanded
   uint64_t curr_key = 0;
   // outcome
   bool found = false;
@@ -322,12 +346,15 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       uint64_t key = calc_index(n.xind, n.yind, n.yawind, P);
       q.nodes.push_back(n);
       q.open.emplace(key, 0);
-      q.heap.push({f, key});
+      q.heap.push_back({f, key});
     }
   }
 
   // ---- device / pinned staging for the rounds
-  const size_t B = nq;
+  // a round expands one node per live query, plus nodes near the top of the open list while few
+  // queries are left (kSpecItems in all, at most kSpecDepth per query)
+  constexpr size_t kSpecItems = 128, kSpecDepth = 8;
+  const size_t B = std::max<size_t>(nq, kSpecItems + kSpecDepth);
   const size_t items = B * NP;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -365,21 +392,100 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   live_ids.reserve(nq);
 
   // ---- lock-step rounds
-  for (;;) {
-    // (1) every live query closes its next node (hybrid_astar.rs:157-161)
-    live_ids.clear();
-    for (uint64_t i = 0; i < nq; ++i) {
-      Query& q = Q[i];
-      if (!q.live) continue;
-      q.curr = -1;
+  const double* mot = plan.motion.data();
+  const uint32_t checks = plan.prm.nlist / plan.prm.check_step + 1;
+  // hybrid_astar.rs:176-209 for the node q.curr from its expansion
+  auto apply = [&](Query& q, const ExpansionView& v) {
+    const PpShotOut& so = *v.shot;
+    q.st.rs_paths += (uint64_t)so.n_paths;
+    q.st.poses_checked += so.poses_handed;
+    if (so.flags & 2u) ++q.st.ambiguous;
+    if (so.flags & (4u | 8u | 16u)) {
+      q.status = (so.flags & 4u) ? PP_ERR_DEGENERATE_RS : (so.flags & 8u) ? PP_ERR_NAN_COST : PP_ERR_NONFINITE;
+      q.live = false;
+      return;
+    }
+    if (so.flags & 1u) {  // update_node_with_analystic_expansion returned Some
+      q.found = true;
+      q.final_parent = q.curr;
+      q.final_rs_idx = so.path_idx;
+      q.final_rs_cost = so.cost;
+      q.live = false;
+      return;
+    }
+    for (uint32_t i = 0; i < NP; ++i) {
+      ++q.st.rollouts;
+      const uint8_t vf = v.valid[i];
+      if (vf & 8u) q.st.poses_checked += checks;
+      if (vf & 2u) ++q.st.ambiguous;
+      if (vf & 4u) {
+        q.status = PP_ERR_NONFINITE;
+        q.live = false;
+        return;
+      }
+      if (!(vf & 1u)) continue;
+      const uint64_t key = calc_index(v.xind[i], v.yind[i], v.yawind[i], P);
+      if (q.closed.count(key)) continue;
+      const double cost = v.cost[i];
+      auto it = q.open.find(key);
+      if (it != q.open.end() && !(q.nodes[it->second].cost > cost)) continue;
+      const double f = v.f[i];
+      if (f != f) {  // NotNan::new(..).unwrap()
+        q.status = PP_ERR_NAN_COST;
+        q.live = false;
+        return;
+      }
+      SNode n;
+      n.xind = v.xind[i];
+      n.yind = v.yind[i];
+      n.yawind = v.yawind[i];
+      n.direction = mot[NP + i] > 0.0 ? 1 : -1;
+      n.x = v.ex[i];
+      n.y = v.ey[i];
+      n.yaw = v.eyaw[i];
+      n.steer = mot[i];
+      n.cost = cost;
+      n.pind = (int64_t)q.curr_key;
+      n.parent = q.curr;
+      n.prim = (int32_t)i;
+      q.nodes.push_back(n);
+      const int32_t id = (int32_t)q.nodes.size() - 1;
+      q.heap.push_back({f, key});
+      std::push_heap(q.heap.begin(), q.heap.end(), HeapLess());
+      if (it == q.open.end())
+        q.open.emplace(key, id);
+      else
+        it->second = id;
+    }
+  };
+  auto view_of = [&](const Expansion& e) {
+    const uint64_t* w = e.words.data();
+    return ExpansionView{&e.shot, e.valid.data(), w, w + NP, (const int64_t*)(w + 2 * NP),
+                         (const double*)(w + 3 * NP), (const double*)(w + 4 * NP), (const double*)(w + 5 * NP),
+                         (const double*)(w + 6 * NP), (const double*)(w + 7 * NP)};
+  };
+  // Closes nodes (hybrid_astar.rs:157-161) for as long as their expansions are already at hand;
+  // returns with q.curr = the node the device has to expand next, or with the query finished.
+  auto advance = [&](Query& q) {
+    if (!q.live) return;
+    for (;;) {
+      if (q.curr >= 0) {
+        auto c = q.cache.find(q.curr);
+        if (c == q.cache.end()) return;
+        apply(q, view_of(c->second));
+        q.cache.erase(c);
+        q.curr = -1;
+        if (!q.live) return;
+      }
       if (ctx->max_expansions && q.st.expansions >= ctx->max_expansions) {
         q.live = false;
         q.status = PP_ERR_LIMIT;
-        continue;
+        return;
       }
       while (!q.open.empty()) {
-        HeapEnt e = q.heap.top();
-        q.heap.pop();
+        std::pop_heap(q.heap.begin(), q.heap.end(), HeapLess());
+        const HeapEnt e = q.heap.back();
+        q.heap.pop_back();
         auto it = q.open.find(e.key);
         if (it == q.open.end()) {
           ++q.st.stale_pops;
@@ -396,26 +502,65 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       if (q.curr < 0) {  // open set exhausted: None
         q.live = false;
         q.status = PP_NO_PATH;
-        continue;
+        return;
       }
-      live_ids.push_back((uint32_t)i);
     }
-    const size_t nl = live_ids.size();
-    if (nl == 0) break;
+  };
+  // Open nodes likely to be closed soon: the best entries among the first levels of the heap.
+  auto speculate = [&](Query& q, size_t depth) {
+    struct Cand {
+      HeapEnt e;
+      int32_t id;
+    };
+    Cand cand[32];
+    size_t nc = 0;
+    const size_t scan = std::min<size_t>(q.heap.size(), 31);
+    for (size_t k = 0; k < scan; ++k) {
+      auto it = q.open.find(q.heap[k].key);
+      if (it == q.open.end()) continue;
+      const int32_t id = it->second;
+      bool dup = q.cache.count(id) != 0;
+      for (size_t j = 0; j < nc && !dup; ++j) dup = cand[j].id == id;  // a key's older entries name the same node
+      if (!dup) cand[nc++] = Cand{q.heap[k], id};
+    }
+    std::sort(cand, cand + nc, [](const Cand& a, const Cand& b) { return HeapLess()(b.e, a.e); });
+    for (size_t k = 0; k < nc && q.want.size() < depth; ++k) q.want.push_back(cand[k].id);
+  };
 
-    // (2) stage parents, launch, fetch.  Inputs and outputs are laid out for this round's
-    // number of live queries, so each direction is one copy of exactly what is used.
+  for (uint64_t i = 0; i < nq; ++i)
+    if (Q[i].live) live_ids.push_back((uint32_t)i);
+  for (;;) {
+    // (1) every live query closes nodes until one needs the device
+    pool.run(live_ids.size(), [&](size_t k) { advance(Q[live_ids[k]]); });
+    size_t nl = 0;
+    for (uint32_t id : live_ids)
+      if (Q[id].live) live_ids[nl++] = id;
+    live_ids.resize(nl);
+    if (nl == 0) break;
+    const size_t depth = std::min<size_t>(kSpecDepth, std::max<size_t>(1, kSpecItems / nl));
+    size_t ni = 0;
+    for (uint32_t id : live_ids) {
+      Query& q = Q[id];
+      q.want.clear();
+      q.want.push_back(q.curr);
+      if (depth > 1) speculate(q, depth);
+      q.item0 = ni;
+      ni += q.want.size();
+    }
+
+    // (2) stage the nodes, launch, fetch.  Inputs and outputs are laid out for this round's number
+    // of items, so each direction is one copy of exactly what is used.
     size_t ro = 0;
     auto rtake = [&](size_t bytes) {
       size_t o = ro;
       ro += al256(bytes);
       return o;
     };
-    const size_t r_q = rtake(6 * nl * 8), r_dir = rtake(nl * 8), r_steer = rtake(nl * 8), r_cost = rtake(nl * 8);
-    const size_t r_hid = rtake(nl * 4);
+    const size_t r_q = rtake(6 * ni * 8), r_dir = rtake(ni * 8), r_steer = rtake(ni * 8), r_cost = rtake(ni * 8);
+    const size_t r_hid = rtake(ni * 4);
     const size_t r_in = ro;
-    const size_t itn = nl * NP;
-    const size_t r_shot = rtake(nl * sizeof(PpShotOut)), r_valid = rtake(itn);
+    const size_t itn = ni * NP;
+    const size_t r_shot = rtake(ni * sizeof(PpShotOut)), r_valid = rtake(itn);
     const size_t r_xind = rtake(itn * 8), r_yind = rtake(itn * 8), r_yaw = rtake(itn * 8), r_c = rtake(itn * 8);
     const size_t r_ex = rtake(itn * 8), r_ey = rtake(itn * 8), r_eyaw = rtake(itn * 8), r_f = rtake(itn * 8);
     const size_t r_out = ro - r_in;
@@ -424,19 +569,22 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     double* hsteer = (double*)(h + r_steer);
     double* hcost = (double*)(h + r_cost);
     int32_t* hhid = (int32_t*)(h + r_hid);
-    for (size_t k = 0; k < nl; ++k) {
-      const Query& q = Q[live_ids[k]];
-      const SNode& n = q.nodes[q.curr];
-      hq[0 * nl + k] = n.x;
-      hq[1 * nl + k] = n.y;
-      hq[2 * nl + k] = n.yaw;
-      hq[3 * nl + k] = q.goal[0];
-      hq[4 * nl + k] = q.goal[1];
-      hq[5 * nl + k] = q.goal[2];
-      hdir[k] = n.direction;
-      hsteer[k] = n.steer;
-      hcost[k] = n.cost;
-      hhid[k] = q.hmap_slot;
+    for (uint32_t id : live_ids) {
+      const Query& q = Q[id];
+      for (size_t j = 0; j < q.want.size(); ++j) {
+        const SNode& n = q.nodes[q.want[j]];
+        const size_t k = q.item0 + j;
+        hq[0 * ni + k] = n.x;
+        hq[1 * ni + k] = n.y;
+        hq[2 * ni + k] = n.yaw;
+        hq[3 * ni + k] = q.goal[0];
+        hq[4 * ni + k] = q.goal[1];
+        hq[5 * ni + k] = q.goal[2];
+        hdir[k] = n.direction;
+        hsteer[k] = n.steer;
+        hcost[k] = n.cost;
+        hhid[k] = q.hmap_slot;
+      }
     }
     PP_HIP(ctx, hipMemcpyAsync(d, h, r_in, hipMemcpyHostToDevice, s));
     eo.valid = (uint8_t*)(d + r_valid);
@@ -450,101 +598,36 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     eo.fcost = (double*)(d + r_f);
     eo.hmap_id = (const int32_t*)(d + r_hid);
     const double* dq = (const double*)(d + r_q);
-    pp_rs_words_launch(ctx, nl, dq, maxc, (PpRsCand*)(d + o_cand), (PpRsPair*)(d + o_pair));
-    pp_rs_shot_launch(ctx, map, conf, (uint32_t)nl, dq, maxc, (const PpRsCand*)(d + o_cand),
+    pp_rs_words_launch(ctx, ni, dq, maxc, (PpRsCand*)(d + o_cand), (PpRsPair*)(d + o_pair));
+    pp_rs_shot_launch(ctx, map, conf, (uint32_t)ni, dq, maxc, (const PpRsCand*)(d + o_cand),
                       (const PpRsPair*)(d + o_pair), (PpShotOut*)(d + r_shot));
-    pp_expand_launch(ctx, map, plan, nl, dq, dq + nl, dq + 2 * nl, (const int64_t*)(d + r_dir),
+    pp_expand_launch(ctx, map, plan, ni, dq, dq + ni, dq + 2 * ni, (const int64_t*)(d + r_dir),
                      (const double*)(d + r_steer), (const double*)(d + r_cost), (const double*)d_mot, eo);
     PP_HIP(ctx, hipGetLastError());
     PP_HIP(ctx, hipMemcpyAsync(h + r_in, d + r_in, r_out, hipMemcpyDeviceToHost, s));
     PP_HIP(ctx, hipStreamSynchronize(s));
 
-    // (3) apply (hybrid_astar.rs:176-209)
+    // (3) the closed node is applied straight from the staging buffer; the nodes fetched ahead of
+    // their turn go into the query's cache
     const PpShotOut* shot = (const PpShotOut*)(h + r_shot);
     const uint8_t* v_valid = (const uint8_t*)(h + r_valid);
-    const uint64_t* v_x = (const uint64_t*)(h + r_xind);
-    const uint64_t* v_y = (const uint64_t*)(h + r_yind);
-    const int64_t* v_yaw = (const int64_t*)(h + r_yaw);
-    const double* v_c = (const double*)(h + r_c);
-    const double* v_ex = (const double*)(h + r_ex);
-    const double* v_ey = (const double*)(h + r_ey);
-    const double* v_eyaw = (const double*)(h + r_eyaw);
-    const double* v_f = (const double*)(h + r_f);
-    const double* mot = plan.motion.data();
+    const char* v_arr[8] = {h + r_xind, h + r_yind, h + r_yaw, h + r_c, h + r_ex, h + r_ey, h + r_eyaw, h + r_f};
     pool.run(nl, [&](size_t k) {
       Query& q = Q[live_ids[k]];
-      const PpShotOut& so = shot[k];
-      q.st.rs_paths += (uint64_t)so.n_paths;
-      q.st.poses_checked += so.poses_handed;
-      if (so.flags & 2u) ++q.st.ambiguous;
-      if (so.flags & 4u) {
-        q.status = PP_ERR_DEGENERATE_RS;
-        q.live = false;
-        return;
+      for (size_t j = 1; j < q.want.size(); ++j) {
+        const size_t it = q.item0 + j;
+        Expansion& e = q.cache[q.want[j]];
+        e.shot = shot[it];
+        e.valid.assign(v_valid + it * NP, v_valid + (it + 1) * NP);
+        e.words.resize(8 * (size_t)NP);
+        for (int a = 0; a < 8; ++a) std::memcpy(e.words.data() + (size_t)a * NP, v_arr[a] + it * NP * 8, (size_t)NP * 8);
       }
-      if (so.flags & 8u) {
-        q.status = PP_ERR_NAN_COST;
-        q.live = false;
-        return;
-      }
-      if (so.flags & 16u) {
-        q.status = PP_ERR_NONFINITE;
-        q.live = false;
-        return;
-      }
-      if (so.flags & 1u) {  // update_node_with_analystic_expansion returned Some
-        q.found = true;
-        q.final_parent = q.curr;
-        q.final_rs_idx = so.path_idx;
-        q.final_rs_cost = so.cost;
-        q.live = false;
-        return;
-      }
-      const size_t base = k * NP;
-      const uint32_t checks = plan.prm.nlist / plan.prm.check_step + 1;
-      for (uint32_t i = 0; i < NP; ++i) {
-        ++q.st.rollouts;
-        const uint8_t vf = v_valid[base + i];
-        if (vf & 8u) q.st.poses_checked += checks;
-        if (vf & 2u) ++q.st.ambiguous;
-        if (vf & 4u) {
-          q.status = PP_ERR_NONFINITE;
-          q.live = false;
-          return;
-        }
-        if (!(vf & 1u)) continue;
-        const uint64_t key = calc_index(v_x[base + i], v_y[base + i], v_yaw[base + i], P);
-        if (q.closed.count(key)) continue;
-        const double cost = v_c[base + i];
-        auto it = q.open.find(key);
-        if (it != q.open.end() && !(q.nodes[it->second].cost > cost)) continue;
-        const double f = v_f[base + i];
-        if (f != f) {  // NotNan::new(..).unwrap()
-          q.status = PP_ERR_NAN_COST;
-          q.live = false;
-          return;
-        }
-        SNode n;
-        n.xind = v_x[base + i];
-        n.yind = v_y[base + i];
-        n.yawind = v_yaw[base + i];
-        n.direction = mot[NP + i] > 0.0 ? 1 : -1;
-        n.x = v_ex[base + i];
-        n.y = v_ey[base + i];
-        n.yaw = v_eyaw[base + i];
-        n.steer = mot[i];
-        n.cost = cost;
-        n.pind = (int64_t)q.curr_key;
-        n.parent = q.curr;
-        n.prim = (int32_t)i;
-        q.nodes.push_back(n);
-        int32_t id = (int32_t)q.nodes.size() - 1;
-        q.heap.push({f, key});
-        if (it == q.open.end())
-          q.open.emplace(key, id);
-        else
-          it->second = id;
-      }
+      const size_t it = q.item0, b = it * NP;
+      const ExpansionView v{&shot[it], v_valid + b, (const uint64_t*)v_arr[0] + b, (const uint64_t*)v_arr[1] + b,
+                            (const int64_t*)v_arr[2] + b, (const double*)v_arr[3] + b, (const double*)v_arr[4] + b,
+                            (const double*)v_arr[5] + b, (const double*)v_arr[6] + b, (const double*)v_arr[7] + b};
+      apply(q, v);
+      q.curr = -1;
     });
   }
   const double t_search = now_ms();

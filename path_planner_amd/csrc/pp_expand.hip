@@ -3,9 +3,20 @@
 //
 // One lane per (parent, primitive).  The yaw recurrence uses tan(u) from a host-computed table
 // (calc_motion_set yields only 2*n_steer-1 distinct steering angles), so every yaw of a rollout
-// is bit-identical to the reference; x and y accumulate device cos/sin.
+// is bit-identical to the reference.  The direction (cos yaw, sin yaw) is evaluated once, at the
+// parent's pose, and turned by the primitive's yaw step from pose to pose (the step's cos and sin
+// come with the motion table): after k steps it is off the libm value of the reference's rounded
+// yaw by at most k (ulp(yaw) + 3 ulp(1)), about 1e-14 over a primitive at |yaw| < 16, which moves
+// a pose by less than 1e-14 m -- five orders below the guard bands of every discrete decision.
 #include "pp_device.h"
 #include "pp_expand.h"
+
+__device__ __forceinline__ void pp_turn(double& c, double& s, double cd, double sd) {
+  const double nc = __builtin_fma(c, cd, -(s * sd));
+  const double ns = __builtin_fma(s, cd, c * sd);
+  c = nc;
+  s = ns;
+}
 
 __global__ void __launch_bounds__(256)
 k_expand(uint64_t n_items, uint32_t n_prim, const double* __restrict__ px,
@@ -18,16 +29,17 @@ k_expand(uint64_t n_items, uint32_t n_prim, const double* __restrict__ px,
     uint64_t p = t / n_prim;
     uint32_t i = (uint32_t)(t - p * n_prim);
     double u = motion[i], d = motion[n_prim + i], tanu = motion[2 * n_prim + i];
+    const double cd = motion[3 * n_prim + i], sd = motion[4 * n_prim + i];
     double x = px[p], y = py[p], yaw = pyaw[p];
     double dm = d * prm.move_step;            // d * conf.move_step
     double dyaw = dm / prm.wheel_base * tanu;  // d * move_step / wheel_base * u.tan()
     unsigned fl = 0;
     bool hit = false;
     uint32_t next_check = 0;
+    double s, c;
+    sincos(yaw, &s, &c);
     for (uint32_t k = 0; k <= prm.nlist; ++k) {
-      double s, c;
       bool check = (k == next_check);
-      if (check || k < prm.nlist) sincos(yaw, &s, &c);
       if (check) {
         next_check += prm.check_step;
         unsigned r = use_lattice ? pp_pose_vs_lattice(x, y, c, s, f, lat)
@@ -40,6 +52,7 @@ k_expand(uint64_t n_items, uint32_t n_prim, const double* __restrict__ px,
         x = x + ax;
         y = y + ay;
         yaw = yaw + dyaw;
+        pp_turn(c, s, cd, sd);
       }
     }
     double vx = x / prm.xyreso, vy = y / prm.xyreso, vyaw = yaw / prm.yawreso;
@@ -101,21 +114,24 @@ __global__ void k_rollout_points(uint32_t n, uint32_t nlist, const double* __res
                                  double* __restrict__ oy, double* __restrict__ oyaw) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  double x = in[j * 5 + 0], y = in[j * 5 + 1], yaw = in[j * 5 + 2], tanu = in[j * 5 + 3],
-         d = in[j * 5 + 4];
+  double x = in[j * 7 + 0], y = in[j * 7 + 1], yaw = in[j * 7 + 2], tanu = in[j * 7 + 3],
+         d = in[j * 7 + 4];
+  const double cd = in[j * 7 + 5], sd = in[j * 7 + 6];
   double dm = d * move_step;
   double dyaw = dm / wheel_base * tanu;
   size_t o = (size_t)j * (nlist + 1);
   ox[o] = x;
   oy[o] = y;
   oyaw[o] = yaw;
+  // the same arithmetic as k_expand, so a node's last point is the pose the search stored for it
+  double s, c;
+  sincos(yaw, &s, &c);
   for (uint32_t k = 0; k < nlist; ++k) {
-    double s, c;
-    sincos(yaw, &s, &c);
     double ax = dm * c, ay = dm * s;
     x = x + ax;
     y = y + ay;
     yaw = yaw + dyaw;
+    pp_turn(c, s, cd, sd);
     ox[o + k + 1] = x;
     oy[o + k + 1] = y;
     oyaw[o + k + 1] = yaw;
@@ -153,9 +169,16 @@ int32_t pp_expand_prepare(pp_ctx* ctx, const pp_map* map, const pp_config* conf,
   uint64_t np = 0;
   pp_motion_set(conf, nullptr, nullptr, 0, &np);
   plan->n_prim = (uint32_t)np;
-  plan->motion.resize(3 * np);
+  // steer | direction | tan(steer) | cos, sin of the yaw step d * move_step / wheel_base * tan(steer)
+  plan->motion.resize(5 * np);
   pp_motion_set(conf, plan->motion.data(), plan->motion.data() + np, np, &np);
-  for (uint64_t i = 0; i < np; ++i) plan->motion[2 * np + i] = std::tan(plan->motion[i]);
+  for (uint64_t i = 0; i < np; ++i) {
+    const double tanu = std::tan(plan->motion[i]);
+    const double dyaw = plan->motion[np + i] * conf->move_step / conf->car.wheel_base * tanu;
+    plan->motion[2 * np + i] = tanu;
+    plan->motion[3 * np + i] = std::cos(dyaw);
+    plan->motion[4 * np + i] = std::sin(dyaw);
+  }
   pp_param P;
   pp_map_param(map, conf, &P);
   plan->param = P;
@@ -272,7 +295,7 @@ extern "C" int32_t pp_expand_batch_dev(pp_ctx* ctx, const pp_map* map, const pp_
   int32_t st = pp_expand_prepare(ctx, map, conf, &plan);
   if (st != PP_OK) return st;
   PP_HIP(ctx, hipSetDevice(ctx->device));
-  // the motion table (steer, direction, tan(steer)) is the only thing staged by the library
+  // the motion table is the only thing staged by the library
   st = pp_scratch_reserve(ctx, al256(plan.motion.size() * 8));
   if (st != PP_OK) return st;
   double* d_mot = (double*)ctx->scratch;
@@ -301,8 +324,14 @@ int32_t pp_rollout_points_batch(pp_ctx* ctx, const pp_config* conf, uint32_t n,
   if (nlist_out) *nlist_out = nlist;
   if (n == 0) return PP_OK;
   PP_HIP(ctx, hipSetDevice(ctx->device));
-  std::vector<double> in(in5, in5 + (size_t)n * 5);
-  for (uint32_t j = 0; j < n; ++j) in[j * 5 + 3] = std::tan(in[j * 5 + 3]);
+  std::vector<double> in((size_t)n * 7);  // x, y, yaw, tan(u), d, cos and sin of the yaw step
+  for (uint32_t j = 0; j < n; ++j) {
+    const double* a = in5 + (size_t)j * 5;
+    const double tanu = std::tan(a[3]);
+    const double dyaw = a[4] * conf->move_step / conf->car.wheel_base * tanu;
+    const double v[7] = {a[0], a[1], a[2], tanu, a[4], std::cos(dyaw), std::sin(dyaw)};
+    std::copy(v, v + 7, in.begin() + (size_t)j * 7);
+  }
   size_t pts = (size_t)n * (nlist + 1);
   size_t in_b = al256(in.size() * 8), o_b = al256(pts * 8);
   int32_t st = pp_scratch_reserve(ctx, in_b + 3 * o_b);

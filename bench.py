@@ -244,7 +244,7 @@ def main():
         last = {}
 
         def step():
-            last["r"] = api.plan_batch(ctx, omap, conf, starts, goals, cap=4096)
+            last["r"] = api.plan_batch(ctx, omap, conf, starts, goals, cap=4096, out=last.get("r"))
 
     # ------------------------------------------------------------------ timed region
     with torch.cuda.stream(stream):

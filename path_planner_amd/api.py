@@ -307,15 +307,19 @@ def hybrid_astar_planning(ctx, omap, conf, sx, sy, syaw, gx, gy, gyaw, cap=20000
             "closed": closed[: min(int(stats.expansions), closed_cap)].copy()}
 
 
-def plan_batch(ctx, omap, conf, starts, goals, cap=4096, closed_cap=0):
+def plan_batch(ctx, omap, conf, starts, goals, cap=4096, closed_cap=0, out=None):
     """n independent hybrid_astar_planning calls advanced together (pp_plan_batch).  Returns
     status[n], a list-like of paths (x, y, yaw, dir arrays of shape (n, cap) with len[n], cost[n])
-    and the per-query statistics."""
+    and the per-query statistics.  `out` = the result of an earlier call of the same shape: its
+    path arrays are written again instead of allocating (and page-faulting in) new ones."""
     starts = np.ascontiguousarray(_f64(starts).reshape(-1, 3))
     goals = np.ascontiguousarray(_f64(goals).reshape(-1, 3))
     n = len(starts)
-    X, Y, YAW = np.zeros((n, cap)), np.zeros((n, cap)), np.zeros((n, cap))
-    D = np.zeros((n, cap), np.int64)
+    if out is not None and out["x"].shape == (n, cap):
+        X, Y, YAW, D = out["x"], out["y"], out["yaw"], out["dir"]
+    else:
+        X, Y, YAW = np.zeros((n, cap)), np.zeros((n, cap)), np.zeros((n, cap))
+        D = np.zeros((n, cap), np.int64)
     closed = np.zeros((n, max(closed_cap, 1)), np.uint64)
     # the pp_path array is filled as a structured numpy array (one vector operation per field)
     pt = np.zeros(n, dtype=[("x", "u8"), ("y", "u8"), ("yaw", "u8"), ("direction", "u8"), ("cap", "u8"),

@@ -57,6 +57,7 @@ extern "C" void pp_ctx_destroy(pp_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->wave_buf) (void)hipFree(ctx->wave_buf);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->plan_buf) (void)hipFree(ctx->plan_buf);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -74,6 +74,9 @@ struct pp_ctx {
   uint64_t wave_stats[4] = {0, 0, 0, 0};  // last relaxation: rounds, tile visits, sweep pairs, tiles
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  // the planner's per-round device staging (grown on demand, never shrunk)
+  void* plan_buf = nullptr;
+  size_t plan_bytes = 0;
 };
 
 struct pp_map {

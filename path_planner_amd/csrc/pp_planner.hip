@@ -186,12 +186,6 @@ struct DevBuf {
     if (p) (void)hipFree(p);
   }
 };
-struct PinBuf {
-  void* p = nullptr;
-  ~PinBuf() {
-    if (p) (void)hipHostFree(p);
-  }
-};
 
 __global__ void k_gather_hmap(uint32_t n, const double* const* __restrict__ tab,
                               const int32_t* __restrict__ slot, const uint64_t* __restrict__ off,
@@ -370,12 +364,18 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   off = io_bytes;
   const size_t o_mot = take(plan.motion.size() * 8);
   const size_t o_cand = take(B * PP_RS_MAX_PATHS * sizeof(PpRsCand)), o_pair = take(B * sizeof(PpRsPair));
-  DevBuf dev;
-  PinBuf pin;
-  PP_HIP(ctx, hipMalloc(&dev.p, off));
-  PP_HIP(ctx, hipHostMalloc(&pin.p, io_bytes, hipHostMallocDefault));
-  char* d = (char*)dev.p;
-  char* h = (char*)pin.p;
+  // both live in the context and are reused by the next batch of the same size
+  if (off > ctx->plan_bytes) {
+    if (ctx->plan_buf) PP_HIP(ctx, hipFree(ctx->plan_buf));
+    ctx->plan_buf = nullptr;
+    ctx->plan_bytes = 0;
+    PP_HIP(ctx, hipMalloc(&ctx->plan_buf, off));
+    ctx->plan_bytes = off;
+  }
+  st = pp_pinned_reserve(ctx, io_bytes);
+  if (st != PP_OK) return st;
+  char* d = (char*)ctx->plan_buf;
+  char* h = (char*)ctx->pinned;
   const double* d_mot = (const double*)(d + o_mot);
   PP_HIP(ctx, hipMemcpyAsync(d + o_mot, plan.motion.data(), plan.motion.size() * 8, hipMemcpyHostToDevice, s));
 
@@ -774,6 +774,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     if (status) status[i] = q.status;
     if (q.status < 0 && ret == PP_OK && !status) ret = q.status;  // per-query codes go to status[]
   }
+  // the queries' maps and node stores are many small allocations: release them on the pool
+  pool.run(nq, [&](size_t i) { Q[i] = Query(); });
+  if (getenv("PP_PLAN_PROFILE")) fprintf(stderr, "[plan] teardown %.1f ms\n", now_ms() - t_extract);
   return ret;
 }
 

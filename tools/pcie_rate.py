@@ -1,5 +1,5 @@
 """PCIe-inclusive rate of the host-pointer collision entry point (pp_collision_batch): the same
-16 M poses handed over as host arrays, copies included.  Not the bench value; quoted in DESIGN.md."""
+16 M poses handed over as host arrays, copies included.  Not the bench value."""
 import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np

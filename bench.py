@@ -174,24 +174,30 @@ def main():
             api.expand_dev(ctx, omap, conf, dpx, dpy, dpyaw, dpdir, dps, dpc, eout)
     elif args.workload == "analytic":
         # analystic_expansion for n (node, goal) pairs: all words, cost order, sampled poses of each
-        # path collision-checked until one is free.  Host-pointer entry point: the 48 B in / 76 B out
-        # per pair cross PCIe inside the timed region (negligible next to the kernels).
+        # path collision-checked until one is free.  Device-pointer entry point: 48 B in / 73 B out
+        # per pair stay in HBM.
         occ = W.occupancy_grid(args.grid, 0.01)
         omap = api.ObstacleMap(ctx, raster=occ)
         n = args.pairs // 4
         q0, q1 = W.rs_pairs(n, start=rank * n, extent=200.0)
         q0[:, :2] += args.grid / 2 - 100.0
         q1[:, :2] += args.grid / 2 - 100.0
-        units, bytes_per_unit = n, 124.0
+        units, bytes_per_unit = n, 121.0
         metric, unit = "analytic_expansion_shots_per_sec", "shots/s"
         wl = {"workload": f"analytic expansion: {n} (node, goal) pairs/GPU within a 200 m box on a "
                           f"{args.grid}x{args.grid} grid (Bernoulli 0.01), demo car and costs",
               "pairs_per_gpu": n, "parallelism": f"pair-sharded x{world}"}
         dtype, kernel = "f64", "k_rs_words+k_rs_shot"
+        q6 = torch.from_numpy(np.ascontiguousarray(np.concatenate([q0.T, q1.T]))).to(dev)
+        a_found = torch.zeros(n, dtype=torch.uint8, device=dev)
+        a_idx = torch.zeros(n, dtype=torch.int32, device=dev)
+        a_np = torch.zeros(n, dtype=torch.int32, device=dev)
+        a_words = torch.zeros((n, 56), dtype=torch.uint8, device=dev)
+        a_cost = torch.zeros(n, dtype=torch.float64, device=dev)
         last = {}
 
         def step():
-            last["r"] = api.analytic_expansion(ctx, omap, conf, q0, q1)
+            api.analytic_expansion_dev(ctx, omap, conf, q6, a_found, a_idx, a_np, a_words, a_cost)
     elif args.workload == "wavefront":
         from path_planner_amd import tiled
         ncell = args.cells
@@ -351,7 +357,7 @@ def main():
             t0 = time.perf_counter()
             st, efound, eidx, enp, ewords, ecost = om.analytic(conf, q0[:ns], q1[:ns])
             dt = time.perf_counter() - t0
-            gfound, gidx = last["r"][0][:ns], last["r"][1][:ns]
+            gfound, gidx = a_found[:ns].cpu().numpy(), a_idx[:ns].cpu().numpy()
             clean = (gfound & 2) == 0
             mism = int((((gfound & 1) != (efound & 1)) & clean).sum() +
                        (((gfound & 1) == 1) & ((efound & 1) == 1) & (gidx != eidx) & clean).sum())

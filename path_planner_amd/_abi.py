@@ -165,6 +165,7 @@ def load_library(path=None):
         "pp_rs_path_cost": (C.c_double, [C.POINTER(RsWord), cfg]),
         "pp_analytic_batch": (C.c_int32, [vp, vp, cfg, C.c_uint64, d, d, d, d, d, d, u8, i32, i32,
                                           C.POINTER(RsWord), d]),
+        "pp_analytic_batch_dev": (C.c_int32, [vp, vp, cfg, C.c_uint64, vp, vp, vp, vp, vp, vp]),
         "pp_plan": (C.c_int32, [vp, vp, cfg, d, d, C.POINTER(Path), C.POINTER(PlanStats)]),
         "pp_plan_batch": (C.c_int32, [vp, vp, cfg, C.c_uint64, d, d, C.POINTER(Path),
                                       C.POINTER(PlanStats), i32]),

@@ -286,6 +286,15 @@ def analytic_expansion(ctx, omap, conf, starts, goals):
     return found, idx, npaths, words, cost
 
 
+def analytic_expansion_dev(ctx, omap, conf, q6, found, idx, npaths, words, cost):
+    """pp_analytic_batch_dev on torch device tensors: q6 float64 (6, n) rows sx, sy, syaw, gx, gy,
+    gyaw; found uint8 (n), idx / npaths int32 (n), words uint8 (n, 56), cost float64 (n)."""
+    n = q6.shape[1]
+    _chk(ctx.lib.pp_analytic_batch_dev(ctx.h, omap.h, C.byref(conf), n, q6.data_ptr(), found.data_ptr(),
+                                       idx.data_ptr(), npaths.data_ptr(), words.data_ptr(),
+                                       cost.data_ptr()), "pp_analytic_batch_dev")
+
+
 # ------------------------------------------------------------------ the planner
 def hybrid_astar_planning(ctx, omap, conf, sx, sy, syaw, gx, gy, gyaw, cap=200000,
                           closed_cap=1 << 20):

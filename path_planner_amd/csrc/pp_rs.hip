@@ -848,6 +848,47 @@ extern "C" double pp_rs_path_cost(const pp_rs_word* w, const pp_config* conf) {
   return rs_cost(w->lengths, word, w->nseg, cost_params(conf));
 }
 
+// PpShotOut records -> the entry point's separate arrays.
+__global__ void k_shot_unpack(uint32_t n, const PpShotOut* __restrict__ o, uint8_t* __restrict__ found,
+                              int32_t* __restrict__ path_idx, int32_t* __restrict__ n_paths,
+                              double* __restrict__ rs_cost) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const PpShotOut r = o[i];
+  found[i] = (uint8_t)(r.flags & 31u);
+  path_idx[i] = r.path_idx;
+  n_paths[i] = r.n_paths;
+  rs_cost[i] = r.path_idx >= 0 ? r.cost : 0.0;
+}
+
+extern "C" int32_t pp_analytic_batch_dev(pp_ctx* ctx, const pp_map* map, const pp_config* conf,
+                                         uint64_t n, const double* d_q6, uint8_t* d_found,
+                                         int32_t* d_path_idx, int32_t* d_n_paths, pp_rs_word* d_word,
+                                         double* d_rs_cost) {
+  if (!ctx || !map || !conf) return PP_ERR_INVALID;
+  if (map->ox.empty()) return PP_ERR_EMPTY_MAP;
+  if (!map->finite) return PP_ERR_NONFINITE;
+  if (n == 0) return PP_OK;
+  if (n > 0x7fffffffu) return PP_ERR_UNSUPPORTED;
+  if (!d_q6 || !d_found || !d_path_idx || !d_n_paths || !d_word || !d_rs_cost) return PP_ERR_INVALID;
+  int32_t st = pp_check_config(conf);
+  if (st != PP_OK) return st;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t ac = al256(n * PP_RS_MAX_PATHS * sizeof(PpRsCand)), ap = al256(n * sizeof(PpRsPair));
+  st = pp_scratch_reserve(ctx, ac + ap + al256(n * sizeof(PpShotOut)));
+  if (st != PP_OK) return st;
+  PpRsCand* d_c = (PpRsCand*)ctx->scratch;
+  PpRsPair* d_p = (PpRsPair*)((char*)d_c + ac);
+  PpShotOut* d_o = (PpShotOut*)((char*)d_p + ap);
+  const double maxc = std::tan(conf->max_steer) / conf->car.wheel_base;  // hybrid_astar.rs:388
+  pp_rs_words_launch(ctx, n, d_q6, maxc, d_c, d_p);
+  pp_rs_shot_launch(ctx, map, conf, (uint32_t)n, d_q6, maxc, d_c, d_p, d_o, d_word);
+  hipLaunchKernelGGL(k_shot_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (uint32_t)n, d_o, d_found, d_path_idx, d_n_paths, d_rs_cost);
+  PP_HIP(ctx, hipGetLastError());
+  return PP_OK;
+}
+
 extern "C" int32_t pp_analytic_batch(pp_ctx* ctx, const pp_map* map, const pp_config* conf,
                                      uint64_t n, const double* sx, const double* sy,
                                      const double* syaw, const double* gx, const double* gy,

@@ -182,6 +182,32 @@ def test_analytic_expansion_vs_oracle(ctx):
         assert np.allclose(words[i].lens(), ewords[i].lens(), rtol=RTOL, atol=1e-9)
 
 
+def test_analytic_expansion_device_form_equals_host_form(ctx):
+    import ctypes as C
+    import torch
+    occ = W.occupancy_grid(256, 0.01)
+    m = api.ObstacleMap(ctx, raster=occ)
+    n = 3000
+    s, g = W.rs_pairs(n, extent=200.0)
+    s[:, :2] += 28.0
+    g[:, :2] += 28.0
+    found, idx, npaths, words, cost = api.analytic_expansion(ctx, m, CONF, s, g)
+    q6 = torch.from_numpy(np.ascontiguousarray(np.concatenate([s.T, g.T]))).cuda()
+    d_found = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    d_idx = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_np = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_words = torch.zeros((n, C.sizeof(A.RsWord)), dtype=torch.uint8, device="cuda")
+    d_cost = torch.zeros(n, dtype=torch.float64, device="cuda")
+    api.analytic_expansion_dev(ctx, m, CONF, q6, d_found, d_idx, d_np, d_words, d_cost)
+    ctx.synchronize()
+    assert ((d_found.cpu().numpy() & 7) == found).all() and (found & 1).sum() > 10
+    assert (d_idx.cpu().numpy() == idx).all() and (d_np.cpu().numpy() == npaths).all()
+    assert (d_cost.cpu().numpy() == cost).all()
+    hw = np.frombuffer(bytes(words), dtype=np.uint8).reshape(n, -1)
+    hit = (found & 1) == 1
+    assert (d_words.cpu().numpy()[hit] == hw[hit]).all()
+
+
 def test_rs_paths_reach_goal_full_batch_property(ctx):
     """1M pairs (the benchmark batch): every best word, integrated by the closed form of its
     segments, ends at the goal pose."""

@@ -82,7 +82,7 @@ def wavefront_obsmap(n=16384, p=0.2, seed=SEED_WAVE_A, kind="bernoulli"):
     """Coarse obstacle raster obs[x, y] for the heuristic benchmark, plus the goal cell.
 
     kind "bernoulli": border + Bernoulli(p).  kind "walls": border + vertical walls every 64
-    columns with one 3-cell gap each (long detours -> many wavefront buckets)."""
+    columns with one 3-cell gap each (long detours -> many relaxation rounds)."""
     if kind == "bernoulli":
         chunk = 1 << 24
         obs = np.empty(n * n, np.uint8)

@@ -287,7 +287,7 @@ def main():
     }
     achieved = units * bytes_per_unit / (dev_ms * 1e-3) / 1e9
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(args.workload),
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(f"wavefront{args.cells}" if args.workload == "wavefront" else args.workload),
                        "kernel": kernel, "kernel_ms": dev_ms, "bytes_per_unit": bytes_per_unit}
     if args.workload == "queries":
         # host-driven search: no single kernel bounds it; report the search's own counters

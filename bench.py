@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--goals", type=int, default=64, help="distinct goals the queries share")
     ap.add_argument("--max-expansions", type=int, default=3000)
     ap.add_argument("--band", type=float, default=0.0, help="relaxation band override (wavefront)")
+    ap.add_argument("--map-kind", default="bernoulli", choices=["bernoulli", "walls"],
+                    help="wavefront obstacle raster: Bernoulli(0.2) or long walls with one gap each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
     return ap.parse_args()
@@ -201,13 +203,14 @@ def main():
     elif args.workload == "wavefront":
         from path_planner_amd import tiled
         ncell = args.cells
-        obs_np, gx, gy = W.wavefront_obsmap(ncell, 0.2)
+        obs_np, gx, gy = W.wavefront_obsmap(ncell, 0.2, kind=args.map_kind)
         x0, x1 = tiled.slab_bounds(ncell, world, rank)
         units, bytes_per_unit = ncell * ncell // world, BYTES_PER_CELL
         metric, unit = "heuristic_cells_per_sec", "cells/s"
         scaling = "strong"
+        mk = "Bernoulli 0.2" if args.map_kind == "bernoulli" else "a wall every 64 columns with one 3-cell gap"
         wl = {"workload": f"holonomic heuristic wavefront, {ncell}x{ncell} grid (border + "
-                          "Bernoulli 0.2), goal at centre", "cells": ncell * ncell,
+                          f"{mk}), goal at centre", "cells": ncell * ncell,
               "parallelism": f"x-slabs x{world}, halo-column exchange" if world > 1 else "1 GPU"}
         dtype, kernel = "f64", "k_tile_round+k_tile_list"
         if world == 1:
@@ -287,7 +290,7 @@ def main():
     }
     achieved = units * bytes_per_unit / (dev_ms * 1e-3) / 1e9
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(f"wavefront{args.cells}" if args.workload == "wavefront" else args.workload),
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(f"wavefront{args.cells}" if args.workload == "wavefront" and args.map_kind == "bernoulli" else args.workload),
                        "kernel": kernel, "kernel_ms": dev_ms, "bytes_per_unit": bytes_per_unit}
     if args.workload == "queries":
         # host-driven search: no single kernel bounds it; report the search's own counters

@@ -678,8 +678,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     if (st != PP_OK) return st;
   }
   // analytic-shot trajectories of all found queries, packed
-  std::vector<double> rx, ry, ryaw, rtotal;
-  std::vector<int64_t> rdir;
+  const double *rx = nullptr, *ry = nullptr, *ryaw = nullptr;
+  const int64_t* rdir = nullptr;
+  std::vector<double> rtotal;
   std::vector<uint32_t> rfl;
   std::vector<uint64_t> roff;
   {
@@ -696,8 +697,8 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       q6[5 * (size_t)nf + k] = q.goal[2];
       sel[k] = q.final_rs_idx;
     }
-    st = pp_rs_selected_batch(ctx, nf, q6.data(), maxc, conf->move_step, sel.data(), roff, rtotal, rfl, rx,
-                              ry, ryaw, rdir);
+    st = pp_rs_selected_batch(ctx, nf, q6.data(), maxc, conf->move_step, sel.data(), roff, rtotal, rfl, &rx,
+                              &ry, &ryaw, &rdir);
     if (st != PP_OK) return st;
   }
   pool.run(nf, [&](size_t k) {

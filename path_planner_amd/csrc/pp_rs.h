@@ -46,10 +46,11 @@ int32_t pp_rs_single(pp_ctx* ctx, const double q[6], double maxc, double step_si
                      double* traj_y, double* traj_yaw, int64_t* traj_dir, uint64_t traj_cap,
                      uint32_t* flags_out);
 // Trajectory of the path with rank sel[i] of each of n pairs (q6 = six host arrays of n), tightly
-// packed: pair i's points are [offs[i], offs[i + 1]) of the output vectors.
+// packed: pair i's points are [offs[i], offs[i + 1]) of the output arrays, which live in the
+// context's pinned buffer until its next use.
 int32_t pp_rs_selected_batch(pp_ctx* ctx, uint32_t n, const double* q6, double maxc, double step_size,
                              const int32_t* sel, std::vector<uint64_t>& offs, std::vector<double>& total,
-                             std::vector<uint32_t>& flags, std::vector<double>& tx, std::vector<double>& ty,
-                             std::vector<double>& tyaw, std::vector<int64_t>& tdir);
+                             std::vector<uint32_t>& flags, const double** tx, const double** ty,
+                             const double** tyaw, const int64_t** tdir);
 
 #endif

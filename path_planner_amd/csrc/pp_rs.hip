@@ -642,8 +642,10 @@ extern "C" int32_t pp_rs_batch(pp_ctx* ctx, uint64_t n, const double* sx, const 
 int32_t pp_rs_selected_batch(pp_ctx* ctx, uint32_t n, const double* q6 /* 6 arrays of n */, double maxc,
                              double step_size, const int32_t* sel, std::vector<uint64_t>& offs,
                              std::vector<double>& total, std::vector<uint32_t>& flags,
-                             std::vector<double>& tx, std::vector<double>& ty, std::vector<double>& tyaw,
-                             std::vector<int64_t>& tdir) {
+                             const double** tx, const double** ty, const double** tyaw,
+                             const int64_t** tdir) {
+  *tx = *ty = *tyaw = nullptr;
+  *tdir = nullptr;
   offs.assign((size_t)n + 1, 0);
   total.assign(n, 0.0);
   flags.assign(n, 0);
@@ -683,10 +685,6 @@ int32_t pp_rs_selected_batch(pp_ctx* ctx, uint32_t n, const double* q6 /* 6 arra
   PP_HIP(ctx, hipStreamSynchronize(s));
   for (uint32_t i = 0; i < n; ++i) offs[i + 1] = offs[i] + np[i];
   const uint64_t tot_pts = offs[n];
-  tx.resize(tot_pts);
-  ty.resize(tot_pts);
-  tyaw.resize(tot_pts);
-  tdir.resize(tot_pts);
   if (tot_pts == 0) return PP_OK;
   // pass 2: the points, packed.  The words are generated again if the scratch buffer has to move.
   const size_t b_t = al256(tot_pts * 8);
@@ -709,11 +707,16 @@ int32_t pp_rs_selected_batch(pp_ctx* ctx, uint32_t n, const double* q6 /* 6 arra
                      step_size, d_c, d_p, d_sel, (const uint64_t*)d_off, d_np, d_tot, d_fl, d_tx, d_ty, d_tyaw,
                      d_td);
   PP_HIP(ctx, hipGetLastError());
-  PP_HIP(ctx, hipMemcpyAsync(tx.data(), d_tx, tot_pts * 8, hipMemcpyDeviceToHost, s));
-  PP_HIP(ctx, hipMemcpyAsync(ty.data(), d_ty, tot_pts * 8, hipMemcpyDeviceToHost, s));
-  PP_HIP(ctx, hipMemcpyAsync(tyaw.data(), d_tyaw, tot_pts * 8, hipMemcpyDeviceToHost, s));
-  PP_HIP(ctx, hipMemcpyAsync(tdir.data(), d_td, tot_pts * 8, hipMemcpyDeviceToHost, s));
+  // the four packed arrays come back in one copy into the context's pinned buffer
+  st = pp_pinned_reserve(ctx, 4 * b_t);
+  if (st != PP_OK) return st;
+  char* hb = (char*)ctx->pinned;
+  PP_HIP(ctx, hipMemcpyAsync(hb, tb, 4 * b_t, hipMemcpyDeviceToHost, s));
   PP_HIP(ctx, hipStreamSynchronize(s));
+  *tx = (const double*)hb;
+  *ty = (const double*)(hb + b_t);
+  *tyaw = (const double*)(hb + 2 * b_t);
+  *tdir = (const int64_t*)(hb + 3 * b_t);
   return PP_OK;
 }
 

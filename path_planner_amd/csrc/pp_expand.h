@@ -45,7 +45,11 @@ int32_t pp_expand_prepare(pp_ctx* ctx, const pp_map* map, const pp_config* conf,
 void pp_expand_launch(pp_ctx* ctx, const pp_map* map, const PpExpandPlan& plan, uint64_t n,
                       const double* d_px, const double* d_py, const double* d_pyaw,
                       const int64_t* d_pdir, const double* d_psteer, const double* d_pcost,
-                      const double* d_motion, PpExpandDev out);
+                      const double* d_motion, PpExpandDev out, uint8_t* d_parent_flag = nullptr);
+// d_parent_flag: n bytes of device scratch, or null.  With it the parents' own poses are tested in
+// a launch of their own (worth it from a few thousand parents on); without it every primitive
+// tests its first pose itself.
+constexpr uint64_t kParentPassMin = 4096;
 int32_t pp_rollout_points_batch(pp_ctx* ctx, const pp_config* conf, uint32_t n, const double* in5,
                                 double* x, double* y, double* yaw, uint32_t* nlist_out);
 

@@ -18,12 +18,29 @@ __device__ __forceinline__ void pp_turn(double& c, double& s, double cd, double 
   s = ns;
 }
 
+// The first pose of every primitive is the parent's own (hybrid_astar.rs:266-268 start the lists
+// with it and is_index_ok samples index 0): for a large batch it is tested once per parent here
+// instead of once per primitive.
+__global__ void __launch_bounds__(256)
+k_parent_pose(uint64_t n, const double* __restrict__ px, const double* __restrict__ py,
+              const double* __restrict__ pyaw, PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice,
+              uint8_t* __restrict__ flag) {
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  double s, c;
+  sincos(pyaw[p], &s, &c);
+  const unsigned r = use_lattice ? pp_pose_vs_lattice(px[p], py[p], c, s, f, lat)
+                                 : pp_pose_vs_buckets(px[p], py[p], c, s, f, bk);
+  flag[p] = (uint8_t)r;
+}
+
 __global__ void __launch_bounds__(256)
 k_expand(uint64_t n_items, uint32_t n_prim, const double* __restrict__ px,
          const double* __restrict__ py, const double* __restrict__ pyaw,
          const int64_t* __restrict__ pdir, const double* __restrict__ psteer,
          const double* __restrict__ pcost, const double* __restrict__ motion, PpExpandParams prm,
-         PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice, PpExpandDev out) {
+         PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice, const uint8_t* __restrict__ pflag,
+         PpExpandDev out) {
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += stride) {
     uint64_t p = t / n_prim;
@@ -42,8 +59,11 @@ k_expand(uint64_t n_items, uint32_t n_prim, const double* __restrict__ px,
       bool check = (k == next_check);
       if (check) {
         next_check += prm.check_step;
-        unsigned r = use_lattice ? pp_pose_vs_lattice(x, y, c, s, f, lat)
-                                 : pp_pose_vs_buckets(x, y, c, s, f, bk);
+        unsigned r;
+        if (k == 0 && pflag)  // uniform over the launch
+          r = pflag[p];
+        else
+          r = use_lattice ? pp_pose_vs_lattice(x, y, c, s, f, lat) : pp_pose_vs_buckets(x, y, c, s, f, bk);
         hit |= (r & PP_F_HIT) && !(r & PP_F_AMBIG);
         fl |= r;
       }
@@ -208,13 +228,16 @@ int32_t pp_expand_prepare(pp_ctx* ctx, const pp_map* map, const pp_config* conf,
 void pp_expand_launch(pp_ctx* ctx, const pp_map* map, const PpExpandPlan& plan, uint64_t n,
                       const double* d_px, const double* d_py, const double* d_pyaw,
                       const int64_t* d_pdir, const double* d_psteer, const double* d_pcost,
-                      const double* d_motion, PpExpandDev out) {
+                      const double* d_motion, PpExpandDev out, uint8_t* d_parent_flag) {
   uint64_t items = n * plan.n_prim;
   const unsigned block = 256;
   unsigned grid = pp_stream_grid(ctx, items, block);
+  if (d_parent_flag)
+    hipLaunchKernelGGL(k_parent_pose, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, ctx->stream, n,
+                       d_px, d_py, d_pyaw, plan.fp, map->lat, map->bk, map->lattice ? 1 : 0, d_parent_flag);
   hipLaunchKernelGGL(k_expand, dim3(grid), dim3(block), 0, ctx->stream, items, plan.n_prim, d_px,
                      d_py, d_pyaw, d_pdir, d_psteer, d_pcost, d_motion, plan.prm, plan.fp, map->lat,
-                     map->bk, map->lattice ? 1 : 0, out);
+                     map->bk, map->lattice ? 1 : 0, (const uint8_t*)d_parent_flag, out);
 }
 
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -235,9 +258,10 @@ extern "C" int32_t pp_expand_batch(pp_ctx* ctx, const pp_map* map, const pp_conf
   uint64_t items = n * plan.n_prim;
   size_t in_b = al256(n * 8), mot_b = al256(plan.motion.size() * 8);
   size_t o8 = al256(items * 8), o1 = al256(items);
-  st = pp_scratch_reserve(ctx, 6 * in_b + mot_b + 7 * o8 + o1);
+  st = pp_scratch_reserve(ctx, 6 * in_b + mot_b + 7 * o8 + o1 + al256(n));
   if (st != PP_OK) return st;
   char* b = (char*)ctx->scratch;
+  uint8_t* d_pf = n >= kParentPassMin ? (uint8_t*)(b + 6 * in_b + mot_b + 7 * o8 + o1) : nullptr;
   double* d_px = (double*)b; b += in_b;
   double* d_py = (double*)b; b += in_b;
   double* d_pyaw = (double*)b; b += in_b;
@@ -262,7 +286,7 @@ extern "C" int32_t pp_expand_batch(pp_ctx* ctx, const pp_map* map, const pp_conf
   PP_HIP(ctx, hipMemcpyAsync(d_ps, psteer, n * 8, hipMemcpyHostToDevice, s));
   PP_HIP(ctx, hipMemcpyAsync(d_pc, pcost, n * 8, hipMemcpyHostToDevice, s));
   PP_HIP(ctx, hipMemcpyAsync(d_mot, plan.motion.data(), plan.motion.size() * 8, hipMemcpyHostToDevice, s));
-  pp_expand_launch(ctx, map, plan, n, d_px, d_py, d_pyaw, d_pdir, d_ps, d_pc, d_mot, o);
+  pp_expand_launch(ctx, map, plan, n, d_px, d_py, d_pyaw, d_pdir, d_ps, d_pc, d_mot, o, d_pf);
   PP_HIP(ctx, hipGetLastError());
   PP_HIP(ctx, hipMemcpyAsync(out->valid, o.valid, items, hipMemcpyDeviceToHost, s));
   PP_HIP(ctx, hipMemcpyAsync(out->xind, o.xind, items * 8, hipMemcpyDeviceToHost, s));
@@ -296,9 +320,10 @@ extern "C" int32_t pp_expand_batch_dev(pp_ctx* ctx, const pp_map* map, const pp_
   if (st != PP_OK) return st;
   PP_HIP(ctx, hipSetDevice(ctx->device));
   // the motion table is the only thing staged by the library
-  st = pp_scratch_reserve(ctx, al256(plan.motion.size() * 8));
+  st = pp_scratch_reserve(ctx, al256(plan.motion.size() * 8) + al256(n));
   if (st != PP_OK) return st;
   double* d_mot = (double*)ctx->scratch;
+  uint8_t* d_pf = n >= kParentPassMin ? (uint8_t*)ctx->scratch + al256(plan.motion.size() * 8) : nullptr;
   PP_HIP(ctx, hipMemcpyAsync(d_mot, plan.motion.data(), plan.motion.size() * 8, hipMemcpyHostToDevice,
                              ctx->stream));
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // plan.motion is a local
@@ -311,7 +336,7 @@ extern "C" int32_t pp_expand_batch_dev(pp_ctx* ctx, const pp_map* map, const pp_
   o.end_x = d_out->end_x;
   o.end_y = d_out->end_y;
   o.end_yaw = d_out->end_yaw;
-  pp_expand_launch(ctx, map, plan, n, d_px, d_py, d_pyaw, d_pdir, d_psteer, d_pcost, d_mot, o);
+  pp_expand_launch(ctx, map, plan, n, d_px, d_py, d_pyaw, d_pdir, d_psteer, d_pcost, d_mot, o, d_pf);
   PP_HIP(ctx, hipGetLastError());
   return PP_OK;
 }

@@ -98,7 +98,7 @@ __device__ __forceinline__ unsigned pp_lattice_scan_exact(double cx, double cy, 
 // The window is the 13 columns floor(gx)-6 .. +6 by the 16 rows of the four block rows (uint4 of
 // the tile) covering floor(gy)-6 .. +6, in window coordinates (origin ix0, yb).  Two rectangles around the true
 // footprint rectangle are used, both from fp32 sin/cos (error < 2e-7) and fp32 arithmetic
-// (error < 5e-5 cells at window coordinates below 32):
+// (error < 1e-4 cells at window coordinates below 64):
 //   * inflated by 2.5e-4 on every side (f.scan_lo, f.scan_wo): rasterised row by row, window
 //     row y spanning [lo(y), hi(y)],
 //       lo(y) = xL + max((y - yL) m1, (y - yL) m2),  hi(y) = xR + min((y - yR) m1, (y - yR) m2),
@@ -113,13 +113,19 @@ __device__ __forceinline__ unsigned pp_lattice_scan_exact(double cx, double cy, 
 
 struct PpScan {
   float xL, yL, xR1, yR, m1, m2;
-  unsigned sh;
+  float c0, c1;  // column range of the window inside the 32-bit tile rows: [c0, c1]
 };
 
 // v_cvt_u32_f32 saturates (negative -> 0, huge -> 0xFFFFFFFF); the C++ cast is undefined there.
 __device__ __forceinline__ unsigned pp_cvt_u32_sat(float v) {
   unsigned r;
   asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+// a - b, 0 when b > a
+__device__ __forceinline__ unsigned pp_sub_sat(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 // ((1 << width) - 1) << offset on the low 5 bits of each operand
@@ -139,15 +145,17 @@ __device__ __forceinline__ unsigned pp_scan_rows4(const PpScan& q, uint4 lb, uns
   for (int r = 0; r < 4; ++r) {
     const float yr = (float)(J0 + r);
     const float t = yr - q.yL, t2 = yr - q.yR;
-    // lo clamped below at 0, hi above at 24, by the three-operand max / min
-    const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(t, q.m1, q.xL), __builtin_fmaf(t, q.m2, q.xL)), 0.0f);
-    const float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaf(t2, q.m1, q.xR1), __builtin_fmaf(t2, q.m2, q.xR1)), 24.0f);
-    const float cl = __builtin_ceilf(lo);
-    const float wf = __builtin_floorf(hi) - cl;  // cells cl .. floor(hi) - 1 (xR1 carries the +1)
-    // empty row: wf <= 0 -> width 0 -> mask 0 whatever the offset's low bits are; width <= 24
-    const unsigned mask = pp_bfm(pp_cvt_u32_sat(wf), pp_cvt_u32_sat(cl));
-    const unsigned bits = lw[r] >> q.sh;  // q.sh <= 15: the 13 window columns stay inside the word
-    k[r] = ((bits & mask) << 4) | (unsigned)(J0 + r);
+    // lo clamped below and hi above to the window's columns by the three-operand max / min
+    const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(t, q.m1, q.xL), __builtin_fmaf(t, q.m2, q.xL)), q.c0);
+    const float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaf(t2, q.m1, q.xR1), __builtin_fmaf(t2, q.m2, q.xR1)), q.c1);
+    // cells ceil(lo) .. floor(hi) - 1 (xR1 carries the +1); the conversion truncates, which is
+    // floor for hi >= 0, and a negative hi becomes 0.  Empty row: width 0 -> mask 0 whatever the
+    // offset's low bits are; width <= 24
+    const unsigned cl = pp_cvt_u32_sat(__builtin_ceilf(lo));
+    const unsigned mask = pp_bfm(pp_sub_sat(pp_cvt_u32_sat(hi), cl), cl);
+    // x coordinates carry the window's bit offset inside the tile row (<= 15, so the 13 window
+    // columns and the masks stay below bit 28): the row word is used as it is
+    k[r] = ((lw[r] & mask) << 4) | (unsigned)(J0 + r);
   }
   return max(max(key, k[0]), max(max(k[1], k[2]), k[3]));
 }
@@ -197,20 +205,24 @@ __device__ __forceinline__ int pp_lattice_filter(double x, double y, float cf, f
   const float s_x = __uint_as_float(__float_as_uint(sf) ^ (__float_as_uint(cf) & 0x80000000u));
   const float c_x = __uint_as_float(__float_as_uint(cf) ^ (__float_as_uint(sf) & 0x80000000u));
   const float vyo = __builtin_fmaf(f.scan_wo, c_x, -(f.scan_lo * s_x));
+  // from here on x is measured in bit positions of the tile row: window column + (ix0 & 15)
+  const float shf = (float)(ix0 & 15);
+  const float wxs = wx + shf;
   PpScan q;
-  q.xL = wx - exo;
+  q.xL = wxs - exo;
   q.yL = wy + vyo;
-  q.xR1 = wx + exo + 1.0f;
+  q.xR1 = wxs + exo + 1.0f;
   q.yR = wy - vyo;
+  q.c0 = shf;
+  q.c1 = shf + 24.0f;
   // edge slopes dx/dy; a vanishing denominator becomes +-1e-30 with its own sign bit
   const float sden = (asf < 1e-30f) ? __builtin_copysignf(1e-30f, sf) : sf;
   const float cden = (acf < 1e-30f) ? __builtin_copysignf(1e-30f, cf) : cf;
   q.m1 = cf * __builtin_amdgcn_rcpf(sden);
   q.m2 = -sf * __builtin_amdgcn_rcpf(cden);
-  q.sh = (unsigned)ix0 & 15u;
 
   // the tile that starts at or before the window's low corner holds all of it: rows ytop & 15 ..
-  // + 12 < 32, columns q.sh .. + 12 < 32; the four block rows from yb are uint4 (yb & 15) >> 2 .. + 3
+  // + 12 < 32, columns (ix0 & 15) .. + 12 < 32; the four block rows from yb are uint4 (yb & 15) >> 2 .. + 3
   const uint4* base = g.tiles + (((size_t)(ix0 >> 4) * (size_t)g.nty + (size_t)(ytop >> 4)) * 8 +
                                  (size_t)((ytop & 15) >> 2));
   const uint4 l1 = base[1], l2 = base[2];
@@ -224,7 +236,7 @@ __device__ __forceinline__ int pp_lattice_filter(double x, double y, float cf, f
     if (key < 16) return 0;
   }
   // one candidate cell against the deflated rectangle
-  const float dx = (float)__builtin_ctz(key >> 4) - wx, dy = (float)(key & 15u) - wy;
+  const float dx = (float)__builtin_ctz(key >> 4) - wxs, dy = (float)(key & 15u) - wy;
   const float u = __builtin_fmaf(dx, cf, dy * sf), v = __builtin_fmaf(dy, cf, -(dx * sf));
   return (__builtin_fabsf(u) < f.scan_li && __builtin_fabsf(v) < f.scan_wi) ? 1 : 2;
 }

@@ -347,7 +347,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   // ---- device / pinned staging for the rounds
   // a round expands one node per live query, plus nodes near the top of the open list while few
   // queries are left (kSpecItems in all, at most kSpecDepth per query)
-  constexpr size_t kSpecItems = 128, kSpecDepth = 8;
+  constexpr size_t kSpecItems = 128, kSpecDepth = 8, kCacheMax = 256;
   const size_t B = std::max<size_t>(nq, kSpecItems + kSpecDepth);
   const size_t items = B * NP;
   size_t off = 0;
@@ -614,6 +614,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     const char* v_arr[8] = {h + r_xind, h + r_yind, h + r_yaw, h + r_c, h + r_ex, h + r_ey, h + r_eyaw, h + r_f};
     pool.run(nl, [&](size_t k) {
       Query& q = Q[live_ids[k]];
+      // entries of nodes that were replaced in the open list are never asked for again: a long
+      // search drops the lot now and then (whatever is still wanted is simply fetched again)
+      if (q.cache.size() > kCacheMax) q.cache.clear();
       for (size_t j = 1; j < q.want.size(); ++j) {
         const size_t it = q.item0 + j;
         Expansion& e = q.cache[q.want[j]];

@@ -53,3 +53,12 @@ def test_missing_library_fails_loudly(tmp_path):
     import pytest
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         A.load_library(str(tmp_path / "libnope.so"))
+
+
+def test_cpp_mirror_header_compiles():
+    """include/path_planner.hpp (the reference's names over the C ABI) is valid C++17 on its own."""
+    import subprocess
+    src = "#include \"path_planner.hpp\"\nint main() { return 0; }\n"
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++",
+                        "-I", os.path.join(ROOT, "include"), "-"], input=src, text=True, capture_output=True)
+    assert r.returncode == 0, r.stderr

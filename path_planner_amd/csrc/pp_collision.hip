@@ -11,8 +11,18 @@ k_collision(uint64_t n, const double* __restrict__ x, const double* __restrict__
             const double* __restrict__ yaw, uint8_t* __restrict__ flags, PpFootprint f,
             PpLattice lat, PpBuckets bk) {
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    double px = x[i], py = y[i], pyaw = yaw[i];
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // the next pose is fetched while the current one is tested
+  double nx = x[i], ny = y[i], nyaw = yaw[i];
+  for (; i < n; i += stride) {
+    const double px = nx, py = ny, pyaw = nyaw;
+    const uint64_t j = i + stride;
+    if (j < n) {
+      nx = x[j];
+      ny = y[j];
+      nyaw = yaw[j];
+    }
     unsigned r;
     if (LATTICE) {
       r = pp_pose_yaw_vs_lattice(px, py, pyaw, f, lat);

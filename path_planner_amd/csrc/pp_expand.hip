@@ -230,8 +230,9 @@ void pp_expand_launch(pp_ctx* ctx, const pp_map* map, const PpExpandPlan& plan, 
                       const int64_t* d_pdir, const double* d_psteer, const double* d_pcost,
                       const double* d_motion, PpExpandDev out, uint8_t* d_parent_flag) {
   uint64_t items = n * plan.n_prim;
-  const unsigned block = 256;
-  unsigned grid = pp_stream_grid(ctx, items, block);
+  const unsigned block = 128;  // with 128 blocks per CU: 714 us on 20 M primitives, 256 x 32 per CU: 729 us
+  const unsigned grid = (unsigned)std::max<uint64_t>(
+      1, std::min<uint64_t>((items + block - 1) / block, (uint64_t)ctx->num_cus * 128));
   if (d_parent_flag)
     hipLaunchKernelGGL(k_parent_pose, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, ctx->stream, n,
                        d_px, d_py, d_pyaw, plan.fp, map->lat, map->bk, map->lattice ? 1 : 0, d_parent_flag);

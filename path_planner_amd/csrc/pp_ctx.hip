@@ -174,7 +174,10 @@ static int32_t build_lattice(pp_ctx* ctx, pp_map* m, const std::vector<int64_t>&
     for (int64_t tx = (gx >> 4) - 1; tx <= (gx >> 4); ++tx)
       for (int64_t ty = (gy >> 4) - 1; ty <= (gy >> 4); ++ty) {
         if (tx < 0 || ty < 0) continue;
-        words[((size_t)tx * (size_t)nty + (size_t)ty) * 32 + (size_t)(gy - 16 * ty)] |= 1u << (gx - 16 * tx);
+        // column c of a tile row sits at bit c + kLatticeShift; the filter never looks past column 27
+        const int64_t col = gx - 16 * tx;
+        if (col + kLatticeShift < 32)
+          words[((size_t)tx * (size_t)nty + (size_t)ty) * 32 + (size_t)(gy - 16 * ty)] |= 1u << (col + kLatticeShift);
       }
   }
   PP_HIP(ctx, hipMalloc((void**)&m->d_tiles, nwords * sizeof(uint32_t)));

@@ -53,7 +53,7 @@ __device__ __forceinline__ void pp_footprint_centre(double x, double y, double c
 // Columns xb .. xb + 15 (xb a multiple of 16) of grid row y, in the low 16 bits.
 __device__ __forceinline__ unsigned pp_lattice_row16(const PpLattice& g, int xb, int y) {
   const uint32_t* w = (const uint32_t*)(g.tiles + ((size_t)(xb >> 4) * (size_t)g.nty + (size_t)(y >> 4)) * 8);
-  return w[y & 15] & 0xFFFFu;
+  return (w[y & 15] >> kLatticeShift) & 0xFFFFu;
 }
 
 // Exhaustive form: the exact predicate on every occupied cell of the rotated rectangle's
@@ -153,9 +153,10 @@ __device__ __forceinline__ unsigned pp_scan_rows4(const PpScan& q, uint4 lb, uns
     // offset's low bits are; width <= 24
     const unsigned cl = pp_cvt_u32_sat(__builtin_ceilf(lo));
     const unsigned mask = pp_bfm(pp_sub_sat(pp_cvt_u32_sat(hi), cl), cl);
-    // x coordinates carry the window's bit offset inside the tile row (<= 15, so the 13 window
-    // columns and the masks stay below bit 28): the row word is used as it is
-    k[r] = ((lw[r] & mask) << 4) | (unsigned)(J0 + r);
+    // x coordinates carry the window's bit position inside the tile row (4 + at most 15, so the 13
+    // window columns and the masks stay below bit 32): the row word is used as it is, and with
+    // its low four bits free the row number goes in with the same instruction (v_and_or_b32)
+    k[r] = (lw[r] & mask) | (unsigned)(J0 + r);
   }
   return max(max(key, k[0]), max(max(k[1], k[2]), k[3]));
 }
@@ -205,8 +206,9 @@ __device__ __forceinline__ int pp_lattice_filter(double x, double y, float cf, f
   const float s_x = __uint_as_float(__float_as_uint(sf) ^ (__float_as_uint(cf) & 0x80000000u));
   const float c_x = __uint_as_float(__float_as_uint(cf) ^ (__float_as_uint(sf) & 0x80000000u));
   const float vyo = __builtin_fmaf(f.scan_wo, c_x, -(f.scan_lo * s_x));
-  // from here on x is measured in bit positions of the tile row: window column + (ix0 & 15)
-  const float shf = (float)(ix0 & 15);
+  // from here on x is measured in bit positions of the tile row: window column + (ix0 & 15) +
+  // kLatticeShift
+  const float shf = (float)((ix0 & 15) + kLatticeShift);
   const float wxs = wx + shf;
   PpScan q;
   q.xL = wxs - exo;
@@ -236,7 +238,7 @@ __device__ __forceinline__ int pp_lattice_filter(double x, double y, float cf, f
     if (key < 16) return 0;
   }
   // one candidate cell against the deflated rectangle
-  const float dx = (float)__builtin_ctz(key >> 4) - wxs, dy = (float)(key & 15u) - wy;
+  const float dx = (float)__builtin_ctz(key >> 4) + (float)kLatticeShift - wxs, dy = (float)(key & 15u) - wy;
   const float u = __builtin_fmaf(dx, cf, dy * sf), v = __builtin_fmaf(dy, cf, -(dx * sf));
   return (__builtin_fabsf(u) < f.scan_li && __builtin_fabsf(v) < f.scan_wi) ? 1 : 2;
 }

@@ -30,14 +30,17 @@ struct PpFootprint {
 };
 
 // Occupancy of an integer-lattice obstacle set, bit-packed for gather locality.
-//   tile  = 32 columns x 32 rows = 128 B = one cache line: word r = row r, bit = column
+//   tile  = 28 columns x 32 rows = 128 B = one cache line: word r = row r, bit kLatticeShift + c
+//   = column c (the low four bits of a row word are zero: the scan-line filter ors its row
+//   number into them)
 //   tiles start every 16 cells in both directions, so they overlap and every cell is stored in
-//   four of them: tile (tx, ty) covers columns [16 tx, 16 tx + 32) and rows [16 ty, 16 ty + 32).
-//   Any window of up to 17 x 17 cells lies inside the tile that starts at or before its low
-//   corner, so a footprint test touches exactly one line however the window falls.
+//   up to four of them: tile (tx, ty) covers columns [16 tx, 16 tx + 28) and rows [16 ty, 16 ty + 32).
+//   Any window of up to 13 columns x 17 rows lies inside the tile that starts at or before its
+//   low corner, so a footprint test touches exactly one line however the window falls.
 //   tile (tx, ty) = tiles[(tx * nty + ty) * 8 .. + 8]  (uint4 k of a tile = rows 4k .. 4k + 3)
 // Cell (cx, cy) in lattice coordinates maps to grid coordinates (cx - x0, cy - y0); the grid is
 // padded with a ring of 32 empty cells so windows near the rim need no per-load bounds test.
+constexpr int kLatticeShift = 4;
 struct PpLattice {
   const uint4* tiles;
   int32_t ntx, nty;

@@ -124,9 +124,7 @@ __device__ __forceinline__ unsigned pp_cvt_u32_sat(float v) {
 }
 // a - b, 0 when b > a
 __device__ __forceinline__ unsigned pp_sub_sat(unsigned a, unsigned b) {
-  unsigned r;
-  asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+  return __builtin_elementwise_sub_sat(a, b);  // v_sub_u32 ... clamp
 }
 // ((1 << width) - 1) << offset on the low 5 bits of each operand
 __device__ __forceinline__ unsigned pp_bfm(unsigned width, unsigned offset) {

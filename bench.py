@@ -40,8 +40,8 @@ BYTES_PER_PRIMITIVE = 57.0 + 48.0 / 78.0  # out: 7 x 8 B + 1 flag byte; in: 48 B
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="collision", choices=["collision", "rs", "wavefront", "queries", "expand", "analytic"])
     ap.add_argument("--poses", type=int, default=1 << 24)
     ap.add_argument("--grid", type=int, default=2048)

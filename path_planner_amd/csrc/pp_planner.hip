@@ -49,6 +49,70 @@ struct SNode {  // data_struct.rs:2-14 without the point lists (regenerated for 
   int32_t prim;      // primitive index that produced it
 };
 
+// calc_index key -> node slot, open addressing with linear probing.  The open and closed sets of
+// a query see a lookup per rollout (78 per closed node) and rarely hold more than a few hundred
+// keys; std::unordered_map spends most of that in its per-node allocations.
+class KeyMap {
+ public:
+  static constexpr int32_t kEmpty = -1, kGone = -2;
+  bool empty() const { return live_ == 0; }
+  int32_t* find(uint64_t key) {
+    if (cap_ == 0) return nullptr;
+    for (size_t i = hash(key) & (cap_ - 1);; i = (i + 1) & (cap_ - 1)) {
+      if (val_[i] == kEmpty) return nullptr;
+      if (val_[i] != kGone && key_[i] == key) return &val_[i];
+    }
+  }
+  bool contains(uint64_t key) { return find(key) != nullptr; }
+  void set(uint64_t key, int32_t v) {  // insert or overwrite
+    if (int32_t* p = find(key)) {
+      *p = v;
+      return;
+    }
+    if ((used_ + 1) * 2 > cap_) grow();
+    size_t i = hash(key) & (cap_ - 1);
+    while (val_[i] >= 0) i = (i + 1) & (cap_ - 1);
+    if (val_[i] == kEmpty) ++used_;
+    key_[i] = key;
+    val_[i] = v;
+    ++live_;
+  }
+  void erase(int32_t* slot) {
+    *slot = kGone;
+    --live_;
+  }
+
+ private:
+  static size_t hash(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    return (size_t)k;
+  }
+  void grow() {
+    std::vector<uint64_t> ok;
+    std::vector<int32_t> ov;
+    ok.swap(key_);
+    ov.swap(val_);
+    cap_ = std::max<size_t>(64, live_ * 4 > cap_ ? cap_ * 2 : cap_);  // tombstones alone do not double it
+    key_.assign(cap_, 0);
+    val_.assign(cap_, kEmpty);
+    used_ = live_ = 0;
+    for (size_t i = 0; i < ov.size(); ++i)
+      if (ov[i] >= 0) {
+        size_t j = hash(ok[i]) & (cap_ - 1);
+        while (val_[j] != kEmpty) j = (j + 1) & (cap_ - 1);
+        key_[j] = ok[i];
+        val_[j] = ov[i];
+        ++used_;
+        ++live_;
+      }
+  }
+  std::vector<uint64_t> key_;
+  std::vector<int32_t> val_;
+  size_t cap_ = 0, used_ = 0, live_ = 0;  // used_ counts tombstones too
+};
+
 struct HeapEnt {
   double f;
   uint64_t key;
@@ -85,7 +149,7 @@ struct Query {
   double start[3], goal[3];
   int32_t hmap_slot = -1;
   std::vector<SNode> nodes;
-  std::unordered_map<uint64_t, int32_t> open, closed;
+  KeyMap open, closed;
   std::vector<HeapEnt> heap;  // std::push_heap / pop_heap under HeapLess
   std::unordered_map<int32_t, Expansion> cache;  // expansions fetched ahead of their node's turn
   std::vector<int32_t> want;                     // nodes to expand in this round, want[0] = curr
@@ -339,7 +403,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       }
       uint64_t key = calc_index(n.xind, n.yind, n.yawind, P);
       q.nodes.push_back(n);
-      q.open.emplace(key, 0);
+      q.open.set(key, 0);
       q.heap.push_back({f, key});
     }
   }
@@ -425,10 +489,10 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       }
       if (!(vf & 1u)) continue;
       const uint64_t key = calc_index(v.xind[i], v.yind[i], v.yawind[i], P);
-      if (q.closed.count(key)) continue;
+      if (q.closed.contains(key)) continue;
       const double cost = v.cost[i];
-      auto it = q.open.find(key);
-      if (it != q.open.end() && !(q.nodes[it->second].cost > cost)) continue;
+      int32_t* it = q.open.find(key);
+      if (it && !(q.nodes[*it].cost > cost)) continue;
       const double f = v.f[i];
       if (f != f) {  // NotNan::new(..).unwrap()
         q.status = PP_ERR_NAN_COST;
@@ -452,10 +516,10 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       const int32_t id = (int32_t)q.nodes.size() - 1;
       q.heap.push_back({f, key});
       std::push_heap(q.heap.begin(), q.heap.end(), HeapLess());
-      if (it == q.open.end())
-        q.open.emplace(key, id);
+      if (!it)
+        q.open.set(key, id);
       else
-        it->second = id;
+        *it = id;
     }
   };
   auto view_of = [&](const Expansion& e) {
@@ -486,15 +550,15 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         std::pop_heap(q.heap.begin(), q.heap.end(), HeapLess());
         const HeapEnt e = q.heap.back();
         q.heap.pop_back();
-        auto it = q.open.find(e.key);
-        if (it == q.open.end()) {
+        int32_t* it = q.open.find(e.key);
+        if (!it) {
           ++q.st.stale_pops;
           continue;
         }
-        q.curr = it->second;
+        q.curr = *it;
         q.curr_key = e.key;
         q.open.erase(it);
-        q.closed[e.key] = q.curr;
+        q.closed.set(e.key, q.curr);
         if (q.st.closed_order && q.st.expansions < q.st.closed_cap) q.st.closed_order[q.st.expansions] = e.key;
         ++q.st.expansions;
         break;
@@ -516,9 +580,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     size_t nc = 0;
     const size_t scan = std::min<size_t>(q.heap.size(), 31);
     for (size_t k = 0; k < scan; ++k) {
-      auto it = q.open.find(q.heap[k].key);
-      if (it == q.open.end()) continue;
-      const int32_t id = it->second;
+      int32_t* it = q.open.find(q.heap[k].key);
+      if (!it) continue;
+      const int32_t id = *it;
       bool dup = q.cache.count(id) != 0;
       for (size_t j = 0; j < nc && !dup; ++j) dup = cand[j].id == id;  // a key's older entries name the same node
       if (!dup) cand[nc++] = Cand{q.heap[k], id};

@@ -56,6 +56,10 @@ class KeyMap {
  public:
   static constexpr int32_t kEmpty = -1, kGone = -2;
   bool empty() const { return live_ == 0; }
+  void clear() {  // keeps the table
+    std::fill(val_.begin(), val_.end(), kEmpty);
+    used_ = live_ = 0;
+  }
   int32_t* find(uint64_t key) {
     if (cap_ == 0) return nullptr;
     for (size_t i = hash(key) & (cap_ - 1);; i = (i + 1) & (cap_ - 1)) {
@@ -163,6 +167,24 @@ struct Query {
   int32_t final_parent = -1;
   int32_t final_rs_idx = -1;
   double final_rs_cost = 0.0;
+  // Back to the state of a fresh query; the containers keep what they have allocated.
+  void reset() {
+    hmap_slot = -1;
+    nodes.clear();
+    open.clear();
+    closed.clear();
+    heap.clear();
+    cache.clear();
+    want.clear();
+    item0 = 0;
+    status = PP_OK;
+    live = false;
+    curr = -1;
+    curr_key = 0;
+    found = false;
+    final_parent = final_rs_idx = -1;
+    final_rs_cost = 0.0;
+  }
   pp_plan_stats st{};
 };
 
@@ -292,11 +314,19 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   st = pp_heuristic_checks(ctx, map, xyreso, dims);
   if (st != PP_OK) return st;
   const uint64_t hxw = dims[4], hyw = dims[5], hcells = hxw * hyw;
-  std::vector<Query> Q(nq);
+  // the query objects live in the context between calls: thousands of small containers are
+  // cheaper to clear than to free and allocate again
+  if (!ctx->plan_state) {
+    ctx->plan_state = new std::vector<Query>();
+    ctx->plan_state_free = [](void* p) { delete (std::vector<Query>*)p; };
+  }
+  std::vector<Query>& Q = *(std::vector<Query>*)ctx->plan_state;
+  if (Q.size() < nq) Q.resize(nq);
   std::unordered_map<uint64_t, int32_t> goal_slot;
   std::vector<std::pair<uint64_t, uint64_t>> goal_cells;
   for (uint64_t i = 0; i < nq; ++i) {
     Query& q = Q[i];
+    q.reset();
     std::memcpy(q.start, starts + 3 * i, 24);
     std::memcpy(q.goal, goals + 3 * i, 24);
     q.st = pp_plan_stats{};
@@ -842,8 +872,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     if (status) status[i] = q.status;
     if (q.status < 0 && ret == PP_OK && !status) ret = q.status;  // per-query codes go to status[]
   }
-  // the queries' maps and node stores are many small allocations: release them on the pool
-  pool.run(nq, [&](size_t i) { Q[i] = Query(); });
+  // a query that grew far beyond the usual gives its memory back; the rest keep theirs
+  for (uint64_t i = 0; i < nq; ++i)
+    if (Q[i].nodes.capacity() > (1u << 16)) Q[i] = Query();
   if (getenv("PP_PLAN_PROFILE")) fprintf(stderr, "[plan] teardown %.1f ms\n", now_ms() - t_extract);
   return ret;
 }

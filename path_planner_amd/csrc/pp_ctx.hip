@@ -58,6 +58,7 @@ extern "C" void pp_ctx_destroy(pp_ctx* ctx) {
   if (ctx->wave_buf) (void)hipFree(ctx->wave_buf);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->plan_buf) (void)hipFree(ctx->plan_buf);
+  if (ctx->hmap_buf) (void)hipFree(ctx->hmap_buf);
   if (ctx->plan_state && ctx->plan_state_free) ctx->plan_state_free(ctx->plan_state);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -80,6 +80,9 @@ struct pp_ctx {
   // the planner's per-round device staging (grown on demand, never shrunk)
   void* plan_buf = nullptr;
   size_t plan_bytes = 0;
+  // the planner's heuristic grids (one per distinct goal cell of the last batch)
+  void* hmap_buf = nullptr;
+  size_t hmap_bytes = 0;
   // the planner's per-query host state, kept between calls (owned by pp_planner.hip)
   void* plan_state = nullptr;
   void (*plan_state_free)(void*) = nullptr;

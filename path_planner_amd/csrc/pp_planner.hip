@@ -266,12 +266,6 @@ class Pool {
 
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
-  }
-};
 
 __global__ void k_gather_hmap(uint32_t n, const double* const* __restrict__ tab,
                               const int32_t* __restrict__ slot, const uint64_t* __restrict__ off,
@@ -350,12 +344,23 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     q.live = true;
   }
   const size_t ngoals = goal_cells.size();
-  DevBuf hm_buf, obs_buf, tab_buf;
+  // heuristic grids, raster and pointer table share one buffer kept in the context
+  struct {
+    void* p = nullptr;
+  } hm_buf, obs_buf, tab_buf;
   std::vector<double*> hm_ptr(ngoals);
   if (ngoals) {
-    PP_HIP(ctx, hipMalloc(&hm_buf.p, ngoals * al256(hcells * 8)));
-    PP_HIP(ctx, hipMalloc(&obs_buf.p, al256(hcells)));
-    PP_HIP(ctx, hipMalloc(&tab_buf.p, ngoals * sizeof(double*)));
+    const size_t b_hm = ngoals * al256(hcells * 8), b_obs = al256(hcells), b_tab = al256(ngoals * sizeof(double*));
+    if (b_hm + b_obs + b_tab > ctx->hmap_bytes) {
+      if (ctx->hmap_buf) PP_HIP(ctx, hipFree(ctx->hmap_buf));
+      ctx->hmap_buf = nullptr;
+      ctx->hmap_bytes = 0;
+      PP_HIP(ctx, hipMalloc(&ctx->hmap_buf, b_hm + b_obs + b_tab));
+      ctx->hmap_bytes = b_hm + b_obs + b_tab;
+    }
+    hm_buf.p = ctx->hmap_buf;
+    obs_buf.p = (char*)ctx->hmap_buf + b_hm;
+    tab_buf.p = (char*)ctx->hmap_buf + b_hm + b_obs;
     st = pp_obsmap_dev(ctx, map, xyreso, 1.0, dims, (uint8_t*)obs_buf.p);
     if (st != PP_OK) return st;
     std::vector<uint64_t> ggx(ngoals), ggy(ngoals);

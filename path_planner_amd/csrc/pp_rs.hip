@@ -315,11 +315,16 @@ __host__ __device__ inline double rs_cost(const double* len, uint32_t word, int 
 }
 
 // ------------------------------------------------------------------ K4: analytic shot, one workgroup per pair
-// (four waves share the sampled poses of a pair, so a lone shot -- the tail of a planner batch --
-// takes a quarter of the time)
+// (the waves of a workgroup share the sampled poses of a pair: four waves finish a lone shot -- the
+// tail of a planner batch -- in a quarter of the time; once the batch alone fills the chip two waves
+// per pair leave fewer lanes idle through the single-lane steps, 4.6 ms against 6.4 ms for 262144
+// pairs)
 
-constexpr int kShotThreads = 256;
+constexpr int kShotThreadsFew = 256;
+constexpr int kShotThreadsBulk = 128;
+constexpr uint32_t kShotBulkMin = 16384;  // pairs; above this every CU holds many workgroups anyway
 
+template <int kShotThreads>
 __global__ void __launch_bounds__(kShotThreads)
 k_rs_shot(uint32_t n, const double* __restrict__ sx, const double* __restrict__ sy,
           const double* __restrict__ syaw, double maxc, double step_size, uint32_t check_step,
@@ -337,16 +342,13 @@ k_rs_shot(uint32_t n, const double* __restrict__ sx, const double* __restrict__ 
   const PpRsPair pr = pairs[pair];
   const PpRsCand* pc = cands + (size_t)pair * PP_RS_MAX_PATHS;
   const int np = pr.n_paths;
-  if (lane == 0) {
-    uint64_t m = pr.accepted;
-    int k = 0;
-    while (m) {
-      gen_of[k++] = (uint8_t)__builtin_ctzll(m);
-      m &= m - 1;
-    }
-  }
+  // path k is the k-th set bit of the accepted mask
+  if (lane < 64 && ((pr.accepted >> lane) & 1ull))
+    gen_of[__builtin_popcountll(pr.accepted & ((1ull << lane) - 1ull))] = (uint8_t)lane;
   __syncthreads();
   const double step = step_size * maxc;
+  // the paths live on the first np lanes of wave 0 (np <= 46) from here to the end
+  uint32_t my_tasks = 0;
   if (lane < np) {
     const PpRsCand c = pc[gen_of[lane]];
     plan_path(c, maxc, step, plans[lane]);
@@ -355,15 +357,17 @@ k_rs_shot(uint32_t n, const double* __restrict__ sx, const double* __restrict__ 
     for (int i = 0; i < 5; ++i) len[i] = c.len[i] / maxc;
     costs[lane] = rs_cost(len, c.word, c.nseg, cp);
     hit[lane] = 0;
+    my_tasks = (uint32_t)((plans[lane].npts + (int)check_step - 1) / (int)check_step);
   }
-  __syncthreads();
-  if (lane == 0) {
-    uint32_t acc = 0;
-    for (int p = 0; p < np; ++p) {
-      task_end[p] = acc;
-      acc += (uint32_t)((plans[p].npts + (int)check_step - 1) / (int)check_step);
+  if (lane < 64) {
+    uint32_t incl = my_tasks;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+      if (lane >= d) incl += up;
     }
-    task_end[np] = acc;
+    if (lane < np) task_end[lane] = incl - my_tasks;
+    if (lane == 63) task_end[np] = incl;
   }
   __syncthreads();
   const uint32_t ntask = np ? task_end[np] : 0u;
@@ -385,32 +389,49 @@ k_rs_shot(uint32_t n, const double* __restrict__ sx, const double* __restrict__ 
     if (r) atomicOr(&hit[p], r);
   }
   __syncthreads();
-  if (lane == 0) {
+  if (lane >= 64) return;
+  // Pop order of BinaryHeap<(Reverse(cost), i)>: cost ascending, ties -> larger i.  Each lane ranks
+  // its own path; the accepted path is the collision-free one of lowest rank, and the paths popped
+  // on the way to it are those of rank up to its rank (all of them when none is free).
+  const bool mine = lane < np;
+  const double myc = mine ? costs[lane] : 0.0;
+  int rank = 0;
+  bool nan_cost = mine && myc != myc;  // NotNan::new(..).unwrap() panics while the heap is filled
+  for (int q = 0; q < np; ++q) {
+    const double cq = costs[q];
+    if (cq < myc || (cq == myc && q > lane)) ++rank;
+  }
+  const uint32_t myhit = mine ? hit[lane] : 0u;
+  const int key = (mine && !(myhit & PP_F_HIT)) ? rank : 0x7fffffff;
+  int best = key;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) best = min(best, __shfl_xor(best, d, 64));
+  const bool popped = mine && rank <= best;
+  uint32_t handed = popped ? my_tasks : 0u;
+  uint32_t fl = 0;
+  if (popped) {
+    if (plans[lane].amb || (myhit & PP_F_AMBIG)) fl |= 2u;
+    if (myhit & PP_F_NONFINITE) fl |= 16u;
+  }
+  if (nan_cost) fl |= 8u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    handed += (uint32_t)__shfl_xor((int)handed, d, 64);
+    fl |= (uint32_t)__shfl_xor((int)fl, d, 64);
+  }
+  const uint64_t winners = __ballot(key == best && best != 0x7fffffff);
+  const int writer = winners ? (int)__builtin_ctzll(winners) : 0;
+  if (lane == writer) {
     PpShotOut o{};
     o.n_paths = np;
-    o.flags = pr.flags;
+    o.flags = pr.flags | fl;
     o.path_idx = -1;
-    // pop order of BinaryHeap<(Reverse(cost), i)>: cost ascending, ties -> larger i
-    uint64_t done = 0;
-    for (int it = 0; it < np; ++it) {
-      int b = -1;
-      for (int p = 0; p < np; ++p) {
-        if ((done >> p) & 1ull) continue;
-        if (b < 0 || costs[p] < costs[b] || (costs[p] == costs[b] && p > b)) b = p;
-      }
-      done |= 1ull << b;
-      o.poses_handed += task_end[b + 1] - task_end[b];
-      if (costs[b] != costs[b]) o.flags |= 8u;  // NaN cost: NotNan::new(..).unwrap() panics
-      if (plans[b].amb) o.flags |= 2u;
-      if (hit[b] & PP_F_NONFINITE) o.flags |= 16u;
-      if (hit[b] & PP_F_AMBIG) o.flags |= 2u;
-      if (!(hit[b] & PP_F_HIT)) {
-        o.path_idx = b;
-        o.gen = gen_of[b];
-        o.cost = costs[b];
-        o.flags |= 1u;
-        break;
-      }
+    o.poses_handed = handed;
+    if (winners) {
+      o.path_idx = lane;
+      o.gen = gen_of[lane];
+      o.cost = myc;
+      o.flags |= 1u;
     }
     out[pair] = o;
     if (word_out) {
@@ -581,9 +602,14 @@ void pp_rs_shot_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, ui
   if (n == 0) return;
   PpFootprint f = pp_make_footprint(conf);
   uint32_t cs = (uint32_t)std::min<uint64_t>(conf->collision_check_step, 0x7fffffffu);
-  hipLaunchKernelGGL(k_rs_shot, dim3(n), dim3(kShotThreads), 0, ctx->stream, n, d_q, d_q + n, d_q + 2 * (size_t)n,
-                     maxc, conf->move_step, cs, cost_params(conf), d_cands, d_pairs, f, map->lat,
-                     map->bk, map->lattice ? 1 : 0, d_out, d_words);
+  if (n >= kShotBulkMin)
+    hipLaunchKernelGGL(k_rs_shot<kShotThreadsBulk>, dim3(n), dim3(kShotThreadsBulk), 0, ctx->stream, n, d_q, d_q + n,
+                       d_q + 2 * (size_t)n, maxc, conf->move_step, cs, cost_params(conf), d_cands, d_pairs, f,
+                       map->lat, map->bk, map->lattice ? 1 : 0, d_out, d_words);
+  else
+    hipLaunchKernelGGL(k_rs_shot<kShotThreadsFew>, dim3(n), dim3(kShotThreadsFew), 0, ctx->stream, n, d_q, d_q + n,
+                       d_q + 2 * (size_t)n, maxc, conf->move_step, cs, cost_params(conf), d_cands, d_pairs, f,
+                       map->lat, map->bk, map->lattice ? 1 : 0, d_out, d_words);
 }
 
 extern "C" int32_t pp_rs_batch_dev(pp_ctx* ctx, uint64_t n, const double* d_sx, const double* d_sy,

@@ -316,32 +316,47 @@ __host__ __device__ inline double rs_cost(const double* len, uint32_t word, int 
 
 // ------------------------------------------------------------------ K4: analytic shot, one workgroup per pair
 // (the waves of a workgroup share the sampled poses of a pair: four waves finish a lone shot -- the
-// tail of a planner batch -- in a quarter of the time; once the batch alone fills the chip two waves
-// per pair leave fewer lanes idle through the single-lane steps, 4.6 ms against 6.4 ms for 262144
-// pairs)
+// tail of a planner batch -- in a quarter of the time; once the batch alone fills the chip one wave
+// per pair keeps every resident wave busy through the steps that only the path lanes take part in:
+// 3.5 ms against 6.4 ms for 262144 pairs)
 
+//
+// A pair has at most 46 paths but rarely more than ten, and the per-path plans in LDS decide how
+// many workgroups a CU holds.  A bulk batch therefore runs twice over the pairs: a pass whose LDS
+// holds kShotFewPaths plans takes the pairs that fit, a pass with room for all 46 takes the rest;
+// a workgroup whose pair belongs to the other pass leaves at once.
+
+#ifndef PP_SHOT_BULK_THREADS
+#define PP_SHOT_BULK_THREADS 64
+#endif
+#ifndef PP_SHOT_FEW_PATHS
+#define PP_SHOT_FEW_PATHS 16
+#endif
 constexpr int kShotThreadsFew = 256;
-constexpr int kShotThreadsBulk = 128;
+constexpr int kShotThreadsBulk = PP_SHOT_BULK_THREADS;
+constexpr int kShotFewPaths = PP_SHOT_FEW_PATHS;
 constexpr uint32_t kShotBulkMin = 16384;  // pairs; above this every CU holds many workgroups anyway
 
-template <int kShotThreads>
+// handles the pairs with np_above < n_paths <= kMaxPaths
+template <int kShotThreads, int kMaxPaths>
 __global__ void __launch_bounds__(kShotThreads)
-k_rs_shot(uint32_t n, const double* __restrict__ sx, const double* __restrict__ sy,
+k_rs_shot(uint32_t n, int np_above, const double* __restrict__ sx, const double* __restrict__ sy,
           const double* __restrict__ syaw, double maxc, double step_size, uint32_t check_step,
           PpCostParams cp, const PpRsCand* __restrict__ cands, const PpRsPair* __restrict__ pairs,
           PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice, PpShotOut* __restrict__ out,
           pp_rs_word* __restrict__ word_out /* optional: the accepted path's word */) {
-  __shared__ PathPlan plans[PP_RS_MAX_PATHS];
-  __shared__ double costs[PP_RS_MAX_PATHS];
-  __shared__ uint32_t hit[PP_RS_MAX_PATHS];
-  __shared__ uint8_t gen_of[PP_RS_MAX_PATHS];
-  __shared__ uint32_t task_end[PP_RS_MAX_PATHS + 1];
+  __shared__ PathPlan plans[kMaxPaths];
+  __shared__ double costs[kMaxPaths];
+  __shared__ uint32_t hit[kMaxPaths];
+  __shared__ uint8_t gen_of[kMaxPaths];
+  __shared__ uint32_t task_end[kMaxPaths + 1];
   const uint32_t pair = blockIdx.x;
   if (pair >= n) return;
   const int lane = threadIdx.x;
   const PpRsPair pr = pairs[pair];
   const PpRsCand* pc = cands + (size_t)pair * PP_RS_MAX_PATHS;
   const int np = pr.n_paths;
+  if (np <= np_above || np > kMaxPaths) return;  // uniform over the workgroup
   // path k is the k-th set bit of the accepted mask
   if (lane < 64 && ((pr.accepted >> lane) & 1ull))
     gen_of[__builtin_popcountll(pr.accepted & ((1ull << lane) - 1ull))] = (uint8_t)lane;
@@ -602,14 +617,17 @@ void pp_rs_shot_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, ui
   if (n == 0) return;
   PpFootprint f = pp_make_footprint(conf);
   uint32_t cs = (uint32_t)std::min<uint64_t>(conf->collision_check_step, 0x7fffffffu);
-  if (n >= kShotBulkMin)
-    hipLaunchKernelGGL(k_rs_shot<kShotThreadsBulk>, dim3(n), dim3(kShotThreadsBulk), 0, ctx->stream, n, d_q, d_q + n,
-                       d_q + 2 * (size_t)n, maxc, conf->move_step, cs, cost_params(conf), d_cands, d_pairs, f,
-                       map->lat, map->bk, map->lattice ? 1 : 0, d_out, d_words);
-  else
-    hipLaunchKernelGGL(k_rs_shot<kShotThreadsFew>, dim3(n), dim3(kShotThreadsFew), 0, ctx->stream, n, d_q, d_q + n,
-                       d_q + 2 * (size_t)n, maxc, conf->move_step, cs, cost_params(conf), d_cands, d_pairs, f,
-                       map->lat, map->bk, map->lattice ? 1 : 0, d_out, d_words);
+#define PP_SHOT_LAUNCH(T, MAXP, ABOVE)                                                                          \
+  hipLaunchKernelGGL((k_rs_shot<T, MAXP>), dim3(n), dim3(T), 0, ctx->stream, n, ABOVE, d_q, d_q + n,               \
+                     d_q + 2 * (size_t)n, maxc, conf->move_step, cs, cost_params(conf), d_cands, d_pairs, f,       \
+                     map->lat, map->bk, map->lattice ? 1 : 0, d_out, d_words)
+  if (n >= kShotBulkMin) {
+    PP_SHOT_LAUNCH(kShotThreadsBulk, kShotFewPaths, -1);
+    PP_SHOT_LAUNCH(kShotThreadsBulk, PP_RS_MAX_PATHS, kShotFewPaths);
+  } else {
+    PP_SHOT_LAUNCH(kShotThreadsFew, PP_RS_MAX_PATHS, -1);
+  }
+#undef PP_SHOT_LAUNCH
 }
 
 extern "C" int32_t pp_rs_batch_dev(pp_ctx* ctx, uint64_t n, const double* d_sx, const double* d_sy,

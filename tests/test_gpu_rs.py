@@ -208,6 +208,36 @@ def test_analytic_expansion_device_form_equals_host_form(ctx):
     assert (d_words.cpu().numpy()[hit] == hw[hit]).all()
 
 
+def test_analytic_expansion_bulk_batch_equals_small_batches(ctx):
+    """A batch large enough for the two-pass bulk launch returns exactly what the same pairs
+    return in small batches (one workgroup shape for all path counts), and the oracle's answers
+    on a sample."""
+    occ = W.occupancy_grid(256, 0.01)
+    m = api.ObstacleMap(ctx, raster=occ)
+    n = 20000
+    s, g = W.rs_pairs(n, extent=200.0)
+    s[:, :2] += 28.0
+    g[:, :2] += 28.0
+    s[:, :2] *= 0.5   # shorter shots: a fair share is collision-free
+    g[:, :2] *= 0.5
+    found, idx, npaths, words, cost = api.analytic_expansion(ctx, m, CONF, s, g)
+    assert npaths.max() > 8 and 100 < (found & 1).sum() < n - 100
+    hw = np.frombuffer(bytes(words), dtype=np.uint8).reshape(n, -1)
+    for a in range(0, n, 5000):
+        f2, i2, n2, w2, c2 = api.analytic_expansion(ctx, m, CONF, s[a:a + 5000], g[a:a + 5000])
+        assert (f2 == found[a:a + 5000]).all() and (i2 == idx[a:a + 5000]).all()
+        assert (n2 == npaths[a:a + 5000]).all() and (c2 == cost[a:a + 5000]).all()
+        assert (np.frombuffer(bytes(w2), dtype=np.uint8).reshape(len(f2), -1) == hw[a:a + 5000]).all()
+    ys, xs = np.nonzero(occ)
+    om = O.OracleMap(xs.astype(np.float64), ys.astype(np.float64))
+    k = 500
+    st, efound, eidx, enp, ewords, ecost = om.analytic(CONF, s[:k], g[:k])
+    ok = (found[:k] & 2) == 0
+    assert ok.mean() > 0.98
+    assert ((found[:k] & 1)[ok] == (efound & 1)[ok]).all() and (idx[:k][ok] == eidx[ok]).all()
+    assert np.allclose(cost[:k][ok], ecost[ok], rtol=RTOL, atol=0)
+
+
 def test_rs_paths_reach_goal_full_batch_property(ctx):
     """1M pairs (the benchmark batch): every best word, integrated by the closed form of its
     segments, ends at the goal pose."""

@@ -1,0 +1,108 @@
+// pp_expand_device.h -- one motion primitive of one parent (calc_next_node + is_index_ok,
+// hybrid_astar.rs:252-343) as a device function, shared by the rollout kernel and the planner's
+// single-launch round.
+#ifndef PP_EXPAND_DEVICE_H
+#define PP_EXPAND_DEVICE_H
+#include "pp_device.h"
+#include "pp_expand.h"
+
+__device__ __forceinline__ void pp_turn(double& c, double& s, double cd, double sd) {
+  const double nc = __builtin_fma(c, cd, -(s * sd));
+  const double ns = __builtin_fma(s, cd, c * sd);
+  c = nc;
+  s = ns;
+}
+
+// Item t = parent t / n_prim, primitive t % n_prim.  pflag, when given, holds the result of the
+// parent's own pose (the first pose of every primitive).
+__device__ __forceinline__ void pp_expand_item(uint64_t t, uint32_t n_prim, const double* __restrict__ px,
+                                               const double* __restrict__ py, const double* __restrict__ pyaw,
+                                               const int64_t* __restrict__ pdir, const double* __restrict__ psteer,
+                                               const double* __restrict__ pcost, const double* __restrict__ motion,
+                                               const PpExpandParams& prm, const PpFootprint& f, const PpLattice& lat,
+                                               const PpBuckets& bk, int use_lattice,
+                                               const uint8_t* __restrict__ pflag, const PpExpandDev& out) {
+  uint64_t p = t / n_prim;
+  uint32_t i = (uint32_t)(t - p * n_prim);
+  double u = motion[i], d = motion[n_prim + i], tanu = motion[2 * n_prim + i];
+  const double cd = motion[3 * n_prim + i], sd = motion[4 * n_prim + i];
+  double x = px[p], y = py[p], yaw = pyaw[p];
+  double dm = d * prm.move_step;            // d * conf.move_step
+  double dyaw = dm / prm.wheel_base * tanu;  // d * move_step / wheel_base * u.tan()
+  unsigned fl = 0;
+  bool hit = false;
+  uint32_t next_check = 0;
+  double s, c;
+  sincos(yaw, &s, &c);
+  for (uint32_t k = 0; k <= prm.nlist; ++k) {
+    bool check = (k == next_check);
+    if (check) {
+      next_check += prm.check_step;
+      unsigned r;
+      if (k == 0 && pflag)  // uniform over the launch
+        r = pflag[p];
+      else
+        r = use_lattice ? pp_pose_vs_lattice(x, y, c, s, f, lat) : pp_pose_vs_buckets(x, y, c, s, f, bk);
+      hit |= (r & PP_F_HIT) && !(r & PP_F_AMBIG);
+      fl |= r;
+    }
+    if (k < prm.nlist) {
+      double ax = dm * c, ay = dm * s;
+      x = x + ax;
+      y = y + ay;
+      yaw = yaw + dyaw;
+      pp_turn(c, s, cd, sd);
+    }
+  }
+  double vx = x / prm.xyreso, vy = y / prm.xyreso, vyaw = yaw / prm.yawreso;
+  uint64_t xind = pp_sat_usize(round(vx));
+  uint64_t yind = pp_sat_usize(round(vy));
+  int64_t yawind = pp_sat_isize(round(vyaw));
+  bool in_bounds = !(xind <= prm.minx || xind >= prm.maxx || yind <= prm.miny || yind >= prm.maxy);
+  // rounding decisions within 1e-9 of a .5 tie could fall either way under another libm
+  bool tie = (fabs(fabs(vx - trunc(vx)) - 0.5) < 1e-9) || (fabs(fabs(vy - trunc(vy)) - 0.5) < 1e-9) ||
+             (fabs(fabs(vyaw - trunc(vyaw)) - 0.5) < 1e-9);
+  bool collide = (fl & PP_F_HIT) != 0;
+  bool amb = tie || (!hit && (fl & PP_F_AMBIG));
+  bool valid = in_bounds && !collide;
+
+  double step = prm.step;
+  double cost = 0.0;
+  int64_t direction;
+  if (d > 0.0) {
+    direction = 1;
+    cost += fabs(step);
+  } else {
+    direction = -1;
+    cost += fabs(step) * prm.backward_cost;
+  }
+  if (direction != pdir[p]) cost += prm.gear_cost;
+  cost += prm.steer_angle_cost * fabs(u);
+  cost += prm.steer_change_cost * fabs(psteer[p] - u);
+  cost += pcost[p];
+
+  // bit3: the index test passed, i.e. the primitive's poses were handed to is_collision
+  unsigned v = (valid ? 1u : 0u) | (amb ? 2u : 0u) | ((fl & PP_F_NONFINITE) ? 4u : 0u) |
+               (in_bounds ? 8u : 0u);
+  out.valid[t] = (uint8_t)v;
+  if (out.fcost) {
+    double fc = 0.0;
+    if (valid) {
+      // is_index_ok guarantees minx < xind < maxx, so the lookup is inside the grid
+      uint64_t hx = xind - prm.minx, hy = yind - prm.miny;
+      const double* hm = out.hmaps[out.hmap_id[p]];
+      fc = (hx < out.hxw && hy < out.hyw) ? cost + out.h_cost * hm[hx * out.hyw + hy]
+                                          : __longlong_as_double(0x7FF8000000000000ll);
+    }
+    out.fcost[t] = fc;
+  }
+  out.xind[t] = valid ? xind : 0;
+  out.yind[t] = valid ? yind : 0;
+  out.yawind[t] = valid ? yawind : 0;
+  out.cost[t] = valid ? cost : 0.0;
+  out.end_x[t] = valid ? x : 0.0;
+  out.end_y[t] = valid ? y : 0.0;
+  out.end_yaw[t] = valid ? yaw : 0.0;
+}
+
+#endif

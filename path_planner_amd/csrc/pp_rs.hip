@@ -9,6 +9,7 @@
 
 #include "pp_rs.h"
 #include "pp_rs_device.h"
+#include "pp_expand_device.h"
 
 namespace {
 
@@ -339,19 +340,17 @@ constexpr uint32_t kShotBulkMin = 16384;  // pairs; above this every CU holds ma
 
 // handles the pairs with np_above < n_paths <= kMaxPaths
 template <int kShotThreads, int kMaxPaths>
-__global__ void __launch_bounds__(kShotThreads)
-k_rs_shot(uint32_t n, int np_above, const double* __restrict__ sx, const double* __restrict__ sy,
-          const double* __restrict__ syaw, double maxc, double step_size, uint32_t check_step,
-          PpCostParams cp, const PpRsCand* __restrict__ cands, const PpRsPair* __restrict__ pairs,
-          PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice, PpShotOut* __restrict__ out,
-          pp_rs_word* __restrict__ word_out /* optional: the accepted path's word */) {
+__device__ __forceinline__ void
+pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, const double* __restrict__ sy,
+             const double* __restrict__ syaw, double maxc, double step_size, uint32_t check_step,
+             const PpCostParams& cp, const PpRsCand* __restrict__ cands, const PpRsPair* __restrict__ pairs,
+             const PpFootprint& f, const PpLattice& lat, const PpBuckets& bk, int use_lattice,
+             PpShotOut* __restrict__ out, pp_rs_word* __restrict__ word_out /* optional: the accepted path's word */) {
   __shared__ PathPlan plans[kMaxPaths];
   __shared__ double costs[kMaxPaths];
   __shared__ uint32_t hit[kMaxPaths];
   __shared__ uint8_t gen_of[kMaxPaths];
   __shared__ uint32_t task_end[kMaxPaths + 1];
-  const uint32_t pair = blockIdx.x;
-  if (pair >= n) return;
   const int lane = threadIdx.x;
   const PpRsPair pr = pairs[pair];
   const PpRsCand* pc = cands + (size_t)pair * PP_RS_MAX_PATHS;
@@ -458,6 +457,47 @@ k_rs_shot(uint32_t n, int np_above, const double* __restrict__ sx, const double*
       word_out[pair] = wz;
     }
   }
+}
+
+template <int kShotThreads, int kMaxPaths>
+__global__ void __launch_bounds__(kShotThreads)
+k_rs_shot(uint32_t n, int np_above, const double* __restrict__ sx, const double* __restrict__ sy,
+          const double* __restrict__ syaw, double maxc, double step_size, uint32_t check_step,
+          PpCostParams cp, const PpRsCand* __restrict__ cands, const PpRsPair* __restrict__ pairs,
+          PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice, PpShotOut* __restrict__ out,
+          pp_rs_word* __restrict__ word_out) {
+  if (blockIdx.x >= n) return;
+  pp_shot_pair<kShotThreads, kMaxPaths>(blockIdx.x, np_above, sx, sy, syaw, maxc, step_size, check_step, cp, cands,
+                                        pairs, f, lat, bk, use_lattice, out, word_out);
+}
+
+// One launch for a planner round of few nodes: workgroups [0, n) take the nodes' analytic shots,
+// the workgroups behind them the nodes' motion primitives (which do not depend on the shots), so
+// the primitives cost the round no time of their own.
+struct PpRoundExpand {
+  const double *px, *py, *pyaw, *psteer, *pcost, *motion;
+  const int64_t* pdir;
+  uint32_t n_prim;
+  PpExpandParams prm;
+  PpExpandDev out;
+};
+
+__global__ void __launch_bounds__(kShotThreadsFew)
+k_round(uint32_t n, const double* __restrict__ sx, const double* __restrict__ sy,
+        const double* __restrict__ syaw, double maxc, double step_size, uint32_t check_step,
+        PpCostParams cp, const PpRsCand* __restrict__ cands, const PpRsPair* __restrict__ pairs,
+        PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice, PpShotOut* __restrict__ out,
+        PpRoundExpand e) {
+  if (blockIdx.x < n) {
+    pp_shot_pair<kShotThreadsFew, PP_RS_MAX_PATHS>(blockIdx.x, -1, sx, sy, syaw, maxc, step_size, check_step, cp,
+                                                   cands, pairs, f, lat, bk, use_lattice, out, nullptr);
+    return;
+  }
+  const uint64_t items = (uint64_t)n * e.n_prim;
+  const uint64_t stride = (uint64_t)(gridDim.x - n) * kShotThreadsFew;
+  for (uint64_t t = (uint64_t)(blockIdx.x - n) * kShotThreadsFew + threadIdx.x; t < items; t += stride)
+    pp_expand_item(t, e.n_prim, e.px, e.py, e.pyaw, e.pdir, e.psteer, e.pcost, e.motion, e.prm, f, lat, bk,
+                   use_lattice, nullptr, e.out);
 }
 
 // ------------------------------------------------------------------ full trajectories of one pair
@@ -628,6 +668,31 @@ void pp_rs_shot_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, ui
     PP_SHOT_LAUNCH(kShotThreadsFew, PP_RS_MAX_PATHS, -1);
   }
 #undef PP_SHOT_LAUNCH
+}
+
+void pp_round_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, const PpExpandPlan& plan, uint32_t n,
+                     const double* d_q, double maxc, const PpRsCand* d_cands, const PpRsPair* d_pairs,
+                     PpShotOut* d_out, const int64_t* d_pdir, const double* d_psteer, const double* d_pcost,
+                     const double* d_motion, PpExpandDev eo) {
+  if (n == 0) return;
+  PpFootprint f = pp_make_footprint(conf);
+  uint32_t cs = (uint32_t)std::min<uint64_t>(conf->collision_check_step, 0x7fffffffu);
+  PpRoundExpand e;
+  e.px = d_q;
+  e.py = d_q + n;
+  e.pyaw = d_q + 2 * (size_t)n;
+  e.pdir = d_pdir;
+  e.psteer = d_psteer;
+  e.pcost = d_pcost;
+  e.motion = d_motion;
+  e.n_prim = plan.n_prim;
+  e.prm = plan.prm;
+  e.out = eo;
+  const uint64_t items = (uint64_t)n * plan.n_prim;
+  const unsigned eb = (unsigned)((items + kShotThreadsFew - 1) / kShotThreadsFew);
+  hipLaunchKernelGGL(k_round, dim3(n + eb), dim3(kShotThreadsFew), 0, ctx->stream, n, d_q, d_q + n,
+                     d_q + 2 * (size_t)n, maxc, conf->move_step, cs, cost_params(conf), d_cands, d_pairs, f, map->lat,
+                     map->bk, map->lattice ? 1 : 0, d_out, e);
 }
 
 extern "C" int32_t pp_rs_batch_dev(pp_ctx* ctx, uint64_t n, const double* d_sx, const double* d_sy,

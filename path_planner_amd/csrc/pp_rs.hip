@@ -255,6 +255,79 @@ __device__ inline void plan_path(const PpRsCand& c, double maxc, double step, Pa
   P.npts = ind + 1;
 }
 
+// plan_path in two steps, for kernels that have lanes to spare.  The heading at a segment's
+// origin is a sum of signed segment lengths and its end point is the origin plus a displacement
+// that depends on that heading and the length only, so all sines and cosines of a path can be
+// taken side by side (one lane per segment); what is left for the path's own lane is additions
+// and the sample counts.  Same operations on the same values as plan_path, hence the same bits.
+__device__ inline void plan_segment(const PpRsCand& c, int i, double maxc, Seg& s) {
+  double oyaw = 0.0;
+  for (int k = 0; k < i; ++k) {
+    const uint32_t t = (c.word >> (4 * k)) & 15u;
+    if (t == 1u) oyaw = oyaw + c.len[k];
+    else if (t != 2u) oyaw = oyaw - c.len[k];
+  }
+  s.type = (int32_t)((c.word >> (4 * i)) & 15u);
+  s.l = c.len[i];
+  s.oyaw = oyaw;
+  sincos(oyaw, &s.so, &s.co);
+  // displacement of the end point, parked in ox / oy until plan_chain turns it into origins
+  double px, py, pyaw;
+  int dir;
+  s.ox = 0.0;
+  s.oy = 0.0;
+  interp(s, s.l, maxc, px, py, pyaw, dir);
+  s.ox = px;
+  s.oy = py;
+}
+
+__device__ inline void plan_chain(const PpRsCand& c, double step, PathPlan& P) {
+  P.nseg = c.nseg;
+  P.dir0 = c.len[0] > 0.0 ? 1 : -1;
+  P.amb = 0;
+  double ll = 0.0;
+  double ox = 0.0, oy = 0.0;
+  int32_t ind = 1;
+  for (int i = 0; i < c.nseg; ++i) {
+    Seg& s = P.seg[i];
+    const double l = c.len[i];
+    const double d = l > 0.0 ? step : -step;
+    const double gdx = s.ox, gdy = s.oy;
+    s.d = d;
+    s.ox = ox;
+    s.oy = oy;
+    double pd0;
+    if (i >= 1 && c.len[i - 1] * c.len[i] > 0.)
+      pd0 = -d - ll;
+    else
+      pd0 = d - ll;
+    s.pd0 = pd0;
+    const int32_t first = ind;
+    s.first = first;
+    int32_t n = 0;
+    const double al = fabs(l);
+    if (fabs(pd0) <= al) {
+      double mm = floor((l - pd0) / d);
+      if (!(mm >= 0.0)) mm = 0.0;
+      if (mm > 1.0e7) mm = 1.0e7;
+      while (fabs(pd0 + (mm + 1.0) * d) <= al) mm += 1.0;
+      while (mm > 0.0 && fabs(pd0 + mm * d) > al) mm -= 1.0;
+      n = (int32_t)mm + 1;
+      if (fabs(fabs(pd0 + mm * d) - al) < PP_RS_GUARD || fabs(fabs(pd0 + (mm + 1.0) * d) - al) < PP_RS_GUARD)
+        P.amb = 1;
+    } else if (fabs(fabs(pd0) - al) < PP_RS_GUARD) {
+      P.amb = 1;
+    }
+    s.n = n;
+    const double pd_exit = pd0 + (double)n * d;
+    ll = l - pd_exit - d;
+    ind = first + n;
+    ox = ox + gdx;
+    oy = oy + gdy;
+  }
+  P.npts = ind + 1;
+}
+
 // Trajectory point j of a planned path in the start frame.
 __device__ inline void local_point(const PathPlan& P, int j, double maxc, double& px, double& py,
                                    double& pyaw, int& dir) {
@@ -290,6 +363,49 @@ __device__ inline void to_global(double lx, double ly, double lyaw, double x0, d
   X = lx * c0 + ly * (-s0) + x0;   // ix cos(-yaw0) + iy sin(-yaw0) + x0
   Y = lx * s0 + ly * c0 + y0;      // -ix sin(-yaw0) + iy cos(-yaw0) + y0
   YAW = pp_pi_2_pi(lyaw + yaw0);
+}
+
+// Pose j of a planned path for the collision test only: position and heading DIRECTION in the
+// global frame.  The heading is the segment origin's heading turned by the arc angle and by the
+// start yaw (two complex products instead of a second sin/cos), and 1/maxc is multiplied instead
+// of divided by: the pose moves by a few ulp (1e-15 m), nine orders below the guard bands of the
+// collision predicate, which report any decision that close to an edge as ambiguous.
+__device__ inline void global_pose_for_test(const PathPlan& P, int j, double rmaxc, double x0, double y0,
+                                            double c0, double s0, double& X, double& Y, double& C, double& S) {
+  double lx = 0.0, ly = 0.0, hc = 1.0, hs = 0.0;
+  if (j != 0) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < 5; ++k)
+      if (k < P.nseg && P.seg[k].first <= j) i = k;
+    const Seg& g = P.seg[i];
+    const int m = j - g.first;
+    const double pd = (m < g.n) ? g.pd0 + (double)m * g.d : g.l;
+    if (g.type == 2) {
+      const double r = pd * rmaxc;
+      lx = g.ox + r * g.co;
+      ly = g.oy + r * g.so;
+      hc = g.co;
+      hs = g.so;
+    } else {
+      double sl, cl;
+      sincos(pd, &sl, &cl);
+      const double ldx = sl * rmaxc;
+      double ldy = (1.0 - cl) * rmaxc;
+      if (g.type != 1) {  // R: mirror image of L
+        ldy = -ldy;
+        sl = -sl;
+      }
+      lx = g.ox + (g.co * ldx - g.so * ldy);
+      ly = g.oy + (g.so * ldx + g.co * ldy);
+      hc = g.co * cl - g.so * sl;
+      hs = g.so * cl + g.co * sl;
+    }
+  }
+  X = lx * c0 - ly * s0 + x0;
+  Y = lx * s0 + ly * c0 + y0;
+  C = hc * c0 - hs * s0;
+  S = hs * c0 + hc * s0;
 }
 
 // hybrid_astar.rs:450-489 on the de-normalised lengths
@@ -362,10 +478,16 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
   __syncthreads();
   const double step = step_size * maxc;
   // the paths live on the first np lanes of wave 0 (np <= 46) from here to the end
+  for (int t = lane; t < np * 5; t += kShotThreads) {
+    const int p = t / 5, i = t - 5 * p;
+    const PpRsCand c = pc[gen_of[p]];
+    if (i < c.nseg) plan_segment(c, i, maxc, plans[p].seg[i]);
+  }
+  __syncthreads();
   uint32_t my_tasks = 0;
   if (lane < np) {
     const PpRsCand c = pc[gen_of[lane]];
-    plan_path(c, maxc, step, plans[lane]);
+    plan_chain(c, step, plans[lane]);
     trim_path(plans[lane], maxc);
     double len[5];
     for (int i = 0; i < 5; ++i) len[i] = c.len[i] / maxc;
@@ -385,7 +507,7 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
   }
   __syncthreads();
   const uint32_t ntask = np ? task_end[np] : 0u;
-  const double x0 = sx[pair], y0 = sy[pair], yaw0 = syaw[pair];
+  const double x0 = sx[pair], y0 = sy[pair], yaw0 = syaw[pair], rmaxc = 1.0 / maxc;
   double s0, c0;
   sincos(yaw0, &s0, &c0);
   for (uint32_t t = lane; t < ntask; t += kShotThreads) {
@@ -393,12 +515,8 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
     for (int k = 1; k < np; ++k)
       if (task_end[k] <= t) p = k;
     int j = (int)(t - task_end[p]) * (int)check_step;
-    double lx, ly, lyaw, X, Y, YAW;
-    int dir;
-    local_point(plans[p], j, maxc, lx, ly, lyaw, dir);
-    to_global(lx, ly, lyaw, x0, y0, yaw0, c0, s0, X, Y, YAW);
-    double s, c;
-    sincos(YAW, &s, &c);
+    double X, Y, c, s;
+    global_pose_for_test(plans[p], j, rmaxc, x0, y0, c0, s0, X, Y, c, s);
     unsigned r = use_lattice ? pp_pose_vs_lattice(X, Y, c, s, f, lat) : pp_pose_vs_buckets(X, Y, c, s, f, bk);
     if (r) atomicOr(&hit[p], r);
   }

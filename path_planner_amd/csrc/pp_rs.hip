@@ -452,6 +452,7 @@ __host__ __device__ inline double rs_cost(const double* len, uint32_t word, int 
 constexpr int kShotThreadsFew = 256;
 constexpr int kShotThreadsBulk = PP_SHOT_BULK_THREADS;
 constexpr int kShotFewPaths = PP_SHOT_FEW_PATHS;
+constexpr uint32_t kShotSettled = 0x80000000u;  // in hit[]: a pose of the path collides beyond doubt
 constexpr uint32_t kShotBulkMin = 16384;  // pairs; above this every CU holds many workgroups anyway
 
 // handles the pairs with np_above < n_paths <= kMaxPaths
@@ -466,7 +467,8 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
   __shared__ double costs[kMaxPaths];
   __shared__ uint32_t hit[kMaxPaths];
   __shared__ uint8_t gen_of[kMaxPaths];
-  __shared__ uint32_t task_end[kMaxPaths + 1];
+  __shared__ uint32_t n_samples[kMaxPaths + 1];  // sampled poses per path; [kMaxPaths]: their maximum
+  __shared__ uint32_t n_settled;
   const int lane = threadIdx.x;
   const PpRsPair pr = pairs[pair];
   const PpRsCand* pc = cands + (size_t)pair * PP_RS_MAX_PATHS;
@@ -495,30 +497,41 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
     hit[lane] = 0;
     my_tasks = (uint32_t)((plans[lane].npts + (int)check_step - 1) / (int)check_step);
   }
+  // sampled poses per path (read by the task loop) and their maximum
+  if (lane < np) n_samples[lane] = my_tasks;
   if (lane < 64) {
-    uint32_t incl = my_tasks;
+    uint32_t mx = my_tasks;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
-      if (lane >= d) incl += up;
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if (lane == 0) {
+      n_samples[kMaxPaths] = mx;
+      n_settled = 0;
     }
-    if (lane < np) task_end[lane] = incl - my_tasks;
-    if (lane == 63) task_end[np] = incl;
   }
   __syncthreads();
-  const uint32_t ntask = np ? task_end[np] : 0u;
+  // Tasks in pose-major order: slot t is sample t / np of path t % np (slots past a path's last
+  // sample are empty), so the early samples of every path come first.  is_collision returns at a
+  // path's first colliding pose, and a path with a clear hit is settled whatever its other poses
+  // say; once every path is settled the remaining samples cannot change the outcome and the
+  // workgroup stops testing.  (A stale count only means a few tests too many.)
+  const uint32_t nslots = np ? n_samples[kMaxPaths] * (uint32_t)np : 0u;
   const double x0 = sx[pair], y0 = sy[pair], yaw0 = syaw[pair], rmaxc = 1.0 / maxc;
   double s0, c0;
   sincos(yaw0, &s0, &c0);
-  for (uint32_t t = lane; t < ntask; t += kShotThreads) {
-    int p = 0;
-    for (int k = 1; k < np; ++k)
-      if (task_end[k] <= t) p = k;
-    int j = (int)(t - task_end[p]) * (int)check_step;
+  for (uint32_t t = lane; t < nslots; t += kShotThreads) {
+    if (*(volatile uint32_t*)&n_settled >= (uint32_t)np) break;
+    const uint32_t k = t / (uint32_t)np;
+    const int p = (int)(t - k * (uint32_t)np);
+    if (k >= n_samples[p]) continue;
+    const int j = (int)k * (int)check_step;
     double X, Y, c, s;
     global_pose_for_test(plans[p], j, rmaxc, x0, y0, c0, s0, X, Y, c, s);
     unsigned r = use_lattice ? pp_pose_vs_lattice(X, Y, c, s, f, lat) : pp_pose_vs_buckets(X, Y, c, s, f, bk);
-    if (r) atomicOr(&hit[p], r);
+    if (r) {
+      const bool clear_hit = (r & PP_F_HIT) && !(r & PP_F_AMBIG);
+      const unsigned old = atomicOr(&hit[p], clear_hit ? (r | kShotSettled) : r);
+      if (clear_hit && !(old & kShotSettled)) atomicAdd(&n_settled, 1u);
+    }
   }
   __syncthreads();
   if (lane >= 64) return;
@@ -542,7 +555,8 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
   uint32_t handed = popped ? my_tasks : 0u;
   uint32_t fl = 0;
   if (popped) {
-    if (plans[lane].amb || (myhit & PP_F_AMBIG)) fl |= 2u;
+    // a guard-band decision on some pose does not matter to a path that has a clear hit elsewhere
+    if (plans[lane].amb || ((myhit & PP_F_AMBIG) && !(myhit & kShotSettled))) fl |= 2u;
     if (myhit & PP_F_NONFINITE) fl |= 16u;
   }
   if (nan_cost) fl |= 8u;

@@ -629,9 +629,17 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
 
   for (uint64_t i = 0; i < nq; ++i)
     if (Q[i].live) live_ids.push_back((uint32_t)i);
+  const bool prof = getenv("PP_PLAN_PROFILE") != nullptr;
+  double p_adv[2] = {0, 0}, p_stage[2] = {0, 0}, p_dev[2] = {0, 0}, p_apply[2] = {0, 0};
+  uint64_t p_rounds[2] = {0, 0}, p_items[2] = {0, 0}, p_live[2] = {0, 0};
+  int pc = 0;
   for (;;) {
     // (1) every live query closes nodes until one needs the device
+    const double p0 = prof ? now_ms() : 0.0;
+    pc = live_ids.size() < 64 ? 1 : 0;
     pool.run(live_ids.size(), [&](size_t k) { advance(Q[live_ids[k]]); });
+    if (prof) p_adv[pc] += now_ms() - p0;
+    const double p1 = prof ? now_ms() : 0.0;
     size_t nl = 0;
     for (uint32_t id : live_ids)
       if (Q[id].live) live_ids[nl++] = id;
@@ -686,6 +694,13 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         hhid[k] = q.hmap_slot;
       }
     }
+    const double p2 = prof ? now_ms() : 0.0;
+    if (prof) {
+      p_stage[pc] += p2 - p1;
+      ++p_rounds[pc];
+      p_items[pc] += ni;
+      p_live[pc] += nl;
+    }
     PP_HIP(ctx, hipMemcpyAsync(d, h, r_in, hipMemcpyHostToDevice, s));
     eo.valid = (uint8_t*)(d + r_valid);
     eo.xind = (uint64_t*)(d + r_xind);
@@ -712,6 +727,8 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     PP_HIP(ctx, hipGetLastError());
     PP_HIP(ctx, hipMemcpyAsync(h + r_in, d + r_in, r_out, hipMemcpyDeviceToHost, s));
     PP_HIP(ctx, hipStreamSynchronize(s));
+    const double p3 = prof ? now_ms() : 0.0;
+    if (prof) p_dev[pc] += p3 - p2;
 
     // (3) the closed node is applied straight from the staging buffer; the nodes fetched ahead of
     // their turn go into the query's cache
@@ -738,8 +755,14 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       apply(q, v);
       q.curr = -1;
     });
+    if (prof) p_apply[pc] += now_ms() - p3;
   }
   const double t_search = now_ms();
+  if (prof)
+    for (int c = 0; c < 2; ++c)
+      fprintf(stderr, "[plan] %s rounds %llu live-sum %llu items %llu | advance %.1f stage %.1f device %.1f apply %.1f ms\n",
+              c ? "small" : "large", (unsigned long long)p_rounds[c], (unsigned long long)p_live[c],
+              (unsigned long long)p_items[c], p_adv[c], p_stage[c], p_dev[c], p_apply[c]);
 
   // ---- extract_path (hybrid_astar.rs:218-250) for the queries that found one: the analytic
   // shots' trajectories and the rollout lists of every node on a final path are regenerated in

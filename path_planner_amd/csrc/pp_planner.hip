@@ -448,6 +448,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   // queries are left (kSpecItems in all, at most kSpecDepth per query)
   constexpr size_t kSpecItems = 128, kSpecDepth = 8, kCacheMax = 256;
   constexpr size_t kRoundFusedMax = 1024;  // nodes; below this a round is one launch after k_rs_words
+  constexpr size_t kRoundDirectMax = 128;  // nodes; below this the kernels work on the pinned staging area
   const size_t B = std::max<size_t>(nq, kSpecItems + kSpecDepth);
   const size_t items = B * NP;
   size_t off = 0;
@@ -701,7 +702,13 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       p_items[pc] += ni;
       p_live[pc] += nl;
     }
-    PP_HIP(ctx, hipMemcpyAsync(d, h, r_in, hipMemcpyHostToDevice, s));
+    // A round of few nodes skips both staging copies (each a blit kernel of its own, with its
+    // launch gap): the kernels read and write the pinned area itself.  Only for few nodes -- every
+    // primitive reads its parent's pose, and over PCIe that does not scale.
+    char* const dw = d;  // the Reeds-Shepp work arrays stay in device memory
+    const bool direct = ni < kRoundDirectMax;
+    char* const d = direct ? h : dw;
+    if (!direct) PP_HIP(ctx, hipMemcpyAsync(d, h, r_in, hipMemcpyHostToDevice, s));
     eo.valid = (uint8_t*)(d + r_valid);
     eo.xind = (uint64_t*)(d + r_xind);
     eo.yind = (uint64_t*)(d + r_yind);
@@ -713,10 +720,10 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     eo.fcost = (double*)(d + r_f);
     eo.hmap_id = (const int32_t*)(d + r_hid);
     const double* dq = (const double*)(d + r_q);
-    pp_rs_words_launch(ctx, ni, dq, maxc, (PpRsCand*)(d + o_cand), (PpRsPair*)(d + o_pair));
+    pp_rs_words_launch(ctx, ni, dq, maxc, (PpRsCand*)(dw + o_cand), (PpRsPair*)(dw + o_pair));
     if (ni < kRoundFusedMax) {
-      pp_round_launch(ctx, map, conf, plan, (uint32_t)ni, dq, maxc, (const PpRsCand*)(d + o_cand),
-                      (const PpRsPair*)(d + o_pair), (PpShotOut*)(d + r_shot), (const int64_t*)(d + r_dir),
+      pp_round_launch(ctx, map, conf, plan, (uint32_t)ni, dq, maxc, (const PpRsCand*)(dw + o_cand),
+                      (const PpRsPair*)(dw + o_pair), (PpShotOut*)(d + r_shot), (const int64_t*)(d + r_dir),
                       (const double*)(d + r_steer), (const double*)(d + r_cost), (const double*)d_mot, eo);
     } else {
       pp_rs_shot_launch(ctx, map, conf, (uint32_t)ni, dq, maxc, (const PpRsCand*)(d + o_cand),
@@ -725,7 +732,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
                        (const double*)(d + r_steer), (const double*)(d + r_cost), (const double*)d_mot, eo);
     }
     PP_HIP(ctx, hipGetLastError());
-    PP_HIP(ctx, hipMemcpyAsync(h + r_in, d + r_in, r_out, hipMemcpyDeviceToHost, s));
+    if (!direct) PP_HIP(ctx, hipMemcpyAsync(h + r_in, d + r_in, r_out, hipMemcpyDeviceToHost, s));
     PP_HIP(ctx, hipStreamSynchronize(s));
     const double p3 = prof ? now_ms() : 0.0;
     if (prof) p_dev[pc] += p3 - p2;

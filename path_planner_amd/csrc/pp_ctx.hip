@@ -55,6 +55,7 @@ extern "C" void pp_ctx_destroy(pp_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->wave_resume && ctx->wave_resume_free) ctx->wave_resume_free(ctx->wave_resume);
   if (ctx->wave_buf) (void)hipFree(ctx->wave_buf);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->plan_buf) (void)hipFree(ctx->plan_buf);

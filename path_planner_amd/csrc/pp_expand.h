@@ -31,6 +31,11 @@ struct PpExpandDev {
   const int32_t* hmap_id = nullptr;      // per parent: index into hmaps
   uint64_t hxw = 0, hyw = 0;
   double h_cost = 0.0;
+  // optional: the grids are final only up to h_limit (a relaxation stopped there).  A valid node
+  // whose grid value is above it, on a cell the raster hobs (same indexing) leaves free, gets
+  // bit 4 of its valid byte: its f cost must not be used.
+  const uint8_t* hobs = nullptr;
+  double h_limit = 0.0;
 };
 
 struct PpExpandPlan {

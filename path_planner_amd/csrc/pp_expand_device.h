@@ -84,18 +84,23 @@ __device__ __forceinline__ void pp_expand_item(uint64_t t, uint32_t n_prim, cons
   // bit3: the index test passed, i.e. the primitive's poses were handed to is_collision
   unsigned v = (valid ? 1u : 0u) | (amb ? 2u : 0u) | ((fl & PP_F_NONFINITE) ? 4u : 0u) |
                (in_bounds ? 8u : 0u);
-  out.valid[t] = (uint8_t)v;
   if (out.fcost) {
     double fc = 0.0;
     if (valid) {
       // is_index_ok guarantees minx < xind < maxx, so the lookup is inside the grid
       uint64_t hx = xind - prm.minx, hy = yind - prm.miny;
       const double* hm = out.hmaps[out.hmap_id[p]];
-      fc = (hx < out.hxw && hy < out.hyw) ? cost + out.h_cost * hm[hx * out.hyw + hy]
-                                          : __longlong_as_double(0x7FF8000000000000ll);
+      if (hx < out.hxw && hy < out.hyw) {
+        const double h = hm[hx * out.hyw + hy];
+        fc = cost + out.h_cost * h;
+        if (out.hobs && h > out.h_limit && !out.hobs[hx * out.hyw + hy]) v |= 16u;
+      } else {
+        fc = __longlong_as_double(0x7FF8000000000000ll);
+      }
     }
     out.fcost[t] = fc;
   }
+  out.valid[t] = (uint8_t)v;
   out.xind[t] = valid ? xind : 0;
   out.yind[t] = valid ? yind : 0;
   out.yawind[t] = valid ? yawind : 0;

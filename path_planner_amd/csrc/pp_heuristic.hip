@@ -177,6 +177,7 @@ struct TileWork {
   uint32_t* status;      // [0] tile visits, [1] sweep pairs, [2] first owned column moved, [3] last
   uint32_t ntiles;
   double band;
+  double limit;          // woken tiles whose key is above it are left pending (+inf: none)
   uint64_t own_first, own_last;  // stored columns whose change is reported in status[2], [3]
 };
 
@@ -285,7 +286,10 @@ __global__ void __launch_bounds__(256) k_tile_unpack(DenseView d, TileGrid g, ui
 }
 
 // Lists the woken tiles whose key is within the band of the lowest pending key; the others stay
-// woken and their keys go into the next round's minimum.  One lane per tile, so the key loads of
+// woken and their keys go into the next round's minimum.  Tiles whose key is above w.limit are
+// never listed: a key is the lowest value that newly appeared next to the tile, values only grow
+// along a path, so when the rounds run dry every cell whose final value is at most the limit has
+// it, and a later run with a higher limit picks up from the pending tiles.  One lane per tile, so the key loads of
 // a crowded stretch of the bitmap are all in flight together.
 __global__ void __launch_bounds__(256) k_tile_list(TileGrid g, TileWork w, uint32_t round) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -302,7 +306,8 @@ __global__ void __launch_bounds__(256) k_tile_list(TileGrid g, TileWork w, uint3
   unsigned long long kb = kInfBits;
   if (woken) {
     kb = w.key[t];
-    take = !(__longlong_as_double((long long)kb) > theta);
+    const double kv = __longlong_as_double((long long)kb);
+    take = !(kv > theta) && !(kv > w.limit);
   }
   // the 32 lanes that share a bitmap word clear their taken bits together
   const unsigned long long tb = __ballot(take);
@@ -603,11 +608,24 @@ struct TileRun {
   TileGrid g{};
   TileWork w{};
   uint32_t nblocks = 0;  // 32x32 blocks (pack / unpack work items)
+  uint32_t round = 0;    // rounds run so far (the work slots rotate with it, so a later run continues the count)
 };
+
+// A relaxation stopped at a cost limit, to be completed later from the same working buffer.
+struct WaveResume {
+  TileRun run;
+  DenseView d;
+  unsigned sg;
+};
+void wave_resume_drop(pp_ctx* ctx) {
+  delete (WaveResume*)ctx->wave_resume;
+  ctx->wave_resume = nullptr;
+}
 
 // Blocked costs, masks and work lists live in a context-owned buffer (grown on demand) so
 // repeated calls do not allocate.
 int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run) {
+  wave_resume_drop(ctx);  // the buffer is about to be overwritten
   const uint64_t ntx = (d.ncols + kTile - 1) / kTile, nty = (d.yw + kTile - 1) / kTile;
   const uint64_t nblocks = ntx * nty;
   const uint64_t nsx = (ntx + 1) / 2, nsy = (nty + 1) / 2, ntiles = nsx * nsy;  // scheduling tiles
@@ -644,6 +662,7 @@ int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run) {
   run->w.minkey = (unsigned long long*)(b + 128);
   run->w.ntiles = (uint32_t)ntiles;
   run->w.band = ctx->wave_band;
+  run->w.limit = __builtin_inf();
   run->w.own_first = d.own_lo;
   run->w.own_last = d.own_hi - 1;
   PP_HIP(ctx, hipMemsetAsync(run->w.bitmap, 0, b_bits, ctx->stream));
@@ -661,7 +680,7 @@ int32_t tile_run(pp_ctx* ctx, TileRun& run, uint64_t* rounds_out, uint32_t statu
   const double diag = std::hypot(1.0, 1.0);  // u_cost((+-1, +-1)), astar.rs:213-215
   const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus * 4, run.w.ntiles);
   const unsigned lgrid = (run.w.ntiles + 255) / 256;
-  uint32_t round = 0;
+  uint32_t round = run.round;
   uint32_t counts[3];
   uint32_t batch = 8;
   for (;;) {
@@ -678,6 +697,7 @@ int32_t tile_run(pp_ctx* ctx, TileRun& run, uint64_t* rounds_out, uint32_t statu
   }
   PP_HIP(ctx, hipMemcpyAsync(status_out, run.w.status, 16, hipMemcpyDeviceToHost, ctx->stream));
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  run.round = round;
   if (rounds_out) *rounds_out = round;
   ctx->wave_stats[0] = round;
   ctx->wave_stats[1] = status_out[0];
@@ -727,9 +747,33 @@ extern "C" int32_t pp_wavefront_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const
 // n grids over one obstacle raster, one goal each, relaxed in the same rounds (the planner's
 // heuristic maps for the distinct goal cells of a batch of queries).  d_cost holds the n dense
 // grids cost_stride doubles apart; goal_x / goal_y are host arrays.
+//
+// With a finite `limit` (and all grids in one pass) the relaxation stops at cells of that value:
+// every cell whose final value is at most the limit has it, the others hold an upper bound or
+// +inf.  The working state stays in the context and pp_wavefront_multi_finish completes the grids;
+// *bounded tells the caller whether that is the case.
+int32_t pp_wavefront_multi_finish(pp_ctx* ctx) {
+  if (!ctx) return PP_ERR_INVALID;
+  WaveResume* r = (WaveResume*)ctx->wave_resume;
+  if (!r) return PP_OK;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  r->run.w.limit = __builtin_inf();
+  uint32_t status[4];
+  int32_t st = tile_run(ctx, r->run, nullptr, status);
+  if (st == PP_OK) {
+    hipLaunchKernelGGL(k_tile_unpack, dim3(r->sg), dim3(256), 0, ctx->stream, r->d, r->run.g, r->run.nblocks);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) st = PP_ERR_HIP;
+  }
+  wave_resume_drop(ctx);
+  return st;
+}
+
 int32_t pp_wavefront_multi_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint8_t* d_obs, uint32_t n,
                                const uint64_t* goal_x, const uint64_t* goal_y, double* d_cost,
-                               uint64_t cost_stride) {
+                               uint64_t cost_stride, double limit, bool* bounded) {
+  if (bounded) *bounded = false;
   if (!ctx || !d_obs || !d_cost || !goal_x || !goal_y) return PP_ERR_INVALID;
   if (n == 0) return PP_OK;
   if (xw == 0 || yw == 0 || xw >= ((uint64_t)1 << 31) || yw >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
@@ -755,6 +799,8 @@ int32_t pp_wavefront_multi_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint
     TileRun run;
     st = tile_prepare(ctx, d, &run);
     if (st != PP_OK) return st;
+    const bool bound = limit < __builtin_inf() && per_pass >= n;
+    if (bound) run.w.limit = limit;
     const unsigned sg = tile_stream_grid(ctx, run.nblocks);
     hipLaunchKernelGGL(k_tile_pack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks, 1);
     hipLaunchKernelGGL(k_seed_goals, dim3((np + 63) / 64), dim3(64), 0, ctx->stream, run.g, run.w, np,
@@ -765,6 +811,11 @@ int32_t pp_wavefront_multi_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint
     hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks);
     PP_HIP(ctx, hipGetLastError());
     PP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // d_goals is reused by the next pass
+    if (bound) {
+      ctx->wave_resume = new WaveResume{run, d, sg};
+      ctx->wave_resume_free = [](void* p) { delete (WaveResume*)p; };
+      if (bounded) *bounded = true;
+    }
   }
   return PP_OK;
 }

@@ -74,6 +74,8 @@ struct pp_ctx {
   void* wave_buf = nullptr;
   size_t wave_bytes = 0;
   double wave_band = 128.0;  // cost band of tiles relaxed in one round
+  void* wave_resume = nullptr;  // state of a relaxation stopped at a cost limit (owned by pp_heuristic.hip)
+  void (*wave_resume_free)(void*) = nullptr;
   uint64_t wave_stats[4] = {0, 0, 0, 0};  // last relaxation: rounds, tile visits, sweep pairs, tiles
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
@@ -118,7 +120,8 @@ struct pp_map {
 int32_t pp_scratch_reserve(pp_ctx* ctx, size_t bytes);
 int32_t pp_wavefront_multi_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint8_t* d_obs, uint32_t n,
                                const uint64_t* goal_x, const uint64_t* goal_y, double* d_cost,
-                               uint64_t cost_stride);
+                               uint64_t cost_stride, double limit = __builtin_inf(), bool* bounded = nullptr);
+int32_t pp_wavefront_multi_finish(pp_ctx* ctx);
 int32_t pp_pinned_reserve(pp_ctx* ctx, size_t bytes);
 PpFootprint pp_make_footprint(const pp_config* conf);
 int32_t pp_check_config(const pp_config* conf);

@@ -344,6 +344,8 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     q.live = true;
   }
   const size_t ngoals = goal_cells.size();
+  double h_limit = __builtin_inf();
+  bool h_bounded = false;
   // heuristic grids, raster and pointer table share one buffer kept in the context
   struct {
     void* p = nullptr;
@@ -369,8 +371,17 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       ggx[g] = goal_cells[g].first;
       ggy[g] = goal_cells[g].second;
     }
+    // The searches only look at the grids near their queries: the relaxation stops at twice the
+    // longest start-goal distance (in cells) plus a margin, where every value up to that limit is
+    // final.  Should a search meet a value beyond it, the grids are completed then (below).
+    double far = 0.0;
+    for (uint64_t i = 0; i < nq; ++i)
+      if (Q[i].live) far = std::max(far, std::hypot(Q[i].start[0] - Q[i].goal[0], Q[i].start[1] - Q[i].goal[1]));
+    h_limit = 2.0 * far / xyreso + 32.0;
+    if (const char* e = getenv("PP_HEURISTIC_LIMIT")) h_limit = atof(e);  // testing: any value is safe
+    if (!(h_limit >= 0.0)) h_limit = __builtin_inf();
     st = pp_wavefront_multi_dev(ctx, hxw, hyw, (const uint8_t*)obs_buf.p, (uint32_t)ngoals, ggx.data(),
-                                ggy.data(), (double*)hm_buf.p, al256(hcells * 8) / 8);
+                                ggy.data(), (double*)hm_buf.p, al256(hcells * 8) / 8, h_limit, &h_bounded);
     if (st != PP_OK) return st;
     PP_HIP(ctx, hipMemcpyAsync(tab_buf.p, hm_ptr.data(), ngoals * sizeof(double*), hipMemcpyHostToDevice, s));
     PP_HIP(ctx, hipStreamSynchronize(s));
@@ -426,6 +437,24 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       PP_HIP(ctx, hipGetLastError());
       PP_HIP(ctx, hipMemcpyAsync(hval.data(), b + b4 + b8, ng * 8, hipMemcpyDeviceToHost, s));
       PP_HIP(ctx, hipStreamSynchronize(s));
+    }
+    if (h_bounded) {
+      // a start cell beyond the limit (blocked cells included: the host does not hold the raster)
+      bool beyond = false;
+      for (size_t k = 0; k < ng; ++k) beyond |= hval[k] > h_limit;
+      if (beyond) {
+        st = pp_wavefront_multi_finish(ctx);
+        if (st != PP_OK) return st;
+        h_bounded = false;
+        const size_t b4 = al256(ng * 4), b8 = al256(ng * 8);
+        char* b = (char*)ctx->scratch;
+        hipLaunchKernelGGL(k_gather_hmap, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
+                           (const double* const*)tab_buf.p, (const int32_t*)b, (const uint64_t*)(b + b4),
+                           (double*)(b + b4 + b8));
+        PP_HIP(ctx, hipGetLastError());
+        PP_HIP(ctx, hipMemcpyAsync(hval.data(), b + b4 + b8, ng * 8, hipMemcpyDeviceToHost, s));
+        PP_HIP(ctx, hipStreamSynchronize(s));
+      }
     }
     for (size_t k = 0; k < ng; ++k) {
       Query& q = Q[g_q[k]];
@@ -485,6 +514,19 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   eo.hxw = hxw;
   eo.hyw = hyw;
   eo.h_cost = conf->h_cost;
+  if (h_bounded) {
+    eo.hobs = (const uint8_t*)obs_buf.p;
+    eo.h_limit = h_limit;
+  }
+  // set by any query whose expansion met a heuristic value beyond the limit: that expansion is
+  // not applied, the grids are completed after the round and the node is expanded again
+  std::atomic<bool> need_grids{false};
+  auto beyond_limit = [&](const ExpansionView& v) {
+    if (!h_bounded) return false;
+    for (uint32_t i = 0; i < NP; ++i)
+      if ((v.valid[i] & 17u) == 17u) return true;
+    return false;
+  };
 
   unsigned hw = std::thread::hardware_concurrency();
   unsigned workers = nq >= 128 ? std::min(15u, hw > 1 ? hw - 1 : 0u) : 0u;
@@ -573,6 +615,10 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       if (q.curr >= 0) {
         auto c = q.cache.find(q.curr);
         if (c == q.cache.end()) return;
+        if (beyond_limit(view_of(c->second))) {  // fetched before the grids were completed
+          q.cache.erase(c);
+          return;
+        }
         apply(q, view_of(c->second));
         q.cache.erase(c);
         q.curr = -1;
@@ -759,9 +805,21 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       const ExpansionView v{&shot[it], v_valid + b, (const uint64_t*)v_arr[0] + b, (const uint64_t*)v_arr[1] + b,
                             (const int64_t*)v_arr[2] + b, (const double*)v_arr[3] + b, (const double*)v_arr[4] + b,
                             (const double*)v_arr[5] + b, (const double*)v_arr[6] + b, (const double*)v_arr[7] + b};
+      if (beyond_limit(v)) {
+        need_grids.store(true, std::memory_order_relaxed);
+        return;  // q.curr stays: the node goes to the device again
+      }
       apply(q, v);
       q.curr = -1;
     });
+    if (need_grids.load(std::memory_order_relaxed)) {
+      st = pp_wavefront_multi_finish(ctx);
+      if (st != PP_OK) return st;
+      h_bounded = false;
+      eo.hobs = nullptr;
+      need_grids.store(false, std::memory_order_relaxed);
+      for (uint32_t id : live_ids) Q[id].cache.clear();  // f costs from the bounded grids
+    }
     if (prof) p_apply[pc] += now_ms() - p3;
   }
   const double t_search = now_ms();

@@ -2,6 +2,7 @@
 grid indices bit-exact, path cost / coordinates to 1e-9 relative."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -194,3 +195,37 @@ def test_plan_batch_many_queries_on_a_large_map_vs_oracle(ctx):
     finally:
         ctx.set_max_expansions(100000)
         O.set_max_expansions(0)
+
+
+def test_bounded_heuristic_grids_do_not_change_a_search(ctx):
+    """The planner relaxes its heuristic grids only up to a cost limit and completes them when a
+    search looks beyond it.  Whatever the limit (PP_HEURISTIC_LIMIT overrides the planner's own
+    choice), closing order, counters and paths are those of the run on complete grids."""
+    occ = W.plan_map(1024)
+    m = api.ObstacleMap(ctx, raster=occ)
+    cs, cg = W.plan_queries(300, 1024, 6)
+    fs = api.collision_flags(ctx, m, CONF, cs[:, 0], cs[:, 1], cs[:, 2])
+    fg = api.collision_flags(ctx, m, CONF, cg[:, 0], cg[:, 1], cg[:, 2])
+    inside = (cs[:, 0] > 8) & (cs[:, 0] < 1015) & (cs[:, 1] > 8) & (cs[:, 1] < 1015)
+    keep = np.nonzero(inside & (fs == 0) & (fg == 0))[0][:64]
+    starts, goals = cs[keep], cg[keep]
+    ctx.set_max_expansions(1500)
+    runs = {}
+    try:
+        for lim in ("inf", None, "40", "3", "0"):
+            if lim is None:
+                os.environ.pop("PP_HEURISTIC_LIMIT", None)
+            else:
+                os.environ["PP_HEURISTIC_LIMIT"] = lim
+            r = api.plan_batch(ctx, m, CONF, starts, goals, cap=4096, closed_cap=1500)
+            runs[lim] = {k: np.array(r[k], copy=True) for k in ("status", "len", "cost", "x", "y", "yaw", "dir", "closed")}
+            runs[lim]["exp"] = np.array([int(s.expansions) for s in r["stats"]])
+            runs[lim]["poses"] = np.array([int(s.poses_checked) for s in r["stats"]])
+    finally:
+        os.environ.pop("PP_HEURISTIC_LIMIT", None)
+        ctx.set_max_expansions(100000)
+    ref = runs["inf"]
+    assert (ref["status"] == 0).sum() >= 50 and ref["exp"].max() > 20
+    for lim, r in runs.items():
+        for k, v in ref.items():
+            assert np.array_equal(v, r[k], equal_nan=True), (lim, k)

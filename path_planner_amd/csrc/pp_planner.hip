@@ -865,6 +865,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     }
     found.push_back(std::move(f));
   }
+  const double x0 = now_ms();
   const uint32_t nf = (uint32_t)found.size();
   const uint32_t pts = plan.prm.nlist + 1;
   const uint32_t nroll_all = (uint32_t)(in5.size() / 5);
@@ -874,6 +875,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     st = pp_rollout_points_batch(ctx, conf, nroll_all, in5.data(), lx.data(), ly.data(), lyaw.data(), &nlist);
     if (st != PP_OK) return st;
   }
+  const double x1 = now_ms();
   // analytic-shot trajectories of all found queries, packed
   const double *rx = nullptr, *ry = nullptr, *ryaw = nullptr;
   const int64_t* rdir = nullptr;
@@ -898,6 +900,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
                               &ry, &ryaw, &rdir);
     if (st != PP_OK) return st;
   }
+  const double x2 = now_ms();
   pool.run(nf, [&](size_t k) {
     const Found& f = found[k];
     Query& q = Q[f.q];
@@ -956,6 +959,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     }
   });
   const double t_extract = now_ms();
+  if (getenv("PP_PLAN_PROFILE"))
+    fprintf(stderr, "[plan] extract: chains %.2f rollouts %.2f rs %.2f assemble %.2f ms (%u rollouts)\n", x0 - t_search,
+            x1 - x0, x2 - x1, t_extract - x2, nroll_all);
   if (getenv("PP_PLAN_PROFILE"))
     fprintf(stderr, "[plan] entry->begin %.1f heur %.1f search(incl. staging alloc) %.1f extract %.1f ms\n", t_begin - t_entry, t_heur - t_begin, t_search - t_heur, t_extract - t_search);
   for (uint64_t i = 0; i < nq; ++i) {

@@ -476,7 +476,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   // a round expands one node per live query, plus nodes near the top of the open list while few
   // queries are left (kSpecItems in all, at most kSpecDepth per query)
   constexpr size_t kSpecItems = 128, kSpecDepth = 8, kCacheMax = 256;
-  constexpr size_t kRoundFusedMax = 1024;  // nodes; below this a round is one launch after k_rs_words
+  constexpr size_t kRoundFusedMax = 1024;  // nodes; below this a round is one launch
   constexpr size_t kRoundDirectMax = 128;  // nodes; below this the kernels work on the pinned staging area
   const size_t B = std::max<size_t>(nq, kSpecItems + kSpecDepth);
   const size_t items = B * NP;
@@ -766,14 +766,14 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     eo.fcost = (double*)(d + r_f);
     eo.hmap_id = (const int32_t*)(d + r_hid);
     const double* dq = (const double*)(d + r_q);
-    pp_rs_words_launch(ctx, ni, dq, maxc, (PpRsCand*)(dw + o_cand), (PpRsPair*)(dw + o_pair));
     if (ni < kRoundFusedMax) {
-      pp_round_launch(ctx, map, conf, plan, (uint32_t)ni, dq, maxc, (const PpRsCand*)(dw + o_cand),
-                      (const PpRsPair*)(dw + o_pair), (PpShotOut*)(d + r_shot), (const int64_t*)(d + r_dir),
-                      (const double*)(d + r_steer), (const double*)(d + r_cost), (const double*)d_mot, eo);
+      pp_round_launch(ctx, map, conf, plan, (uint32_t)ni, dq, maxc, (PpShotOut*)(d + r_shot),
+                      (const int64_t*)(d + r_dir), (const double*)(d + r_steer), (const double*)(d + r_cost),
+                      (const double*)d_mot, eo);
     } else {
-      pp_rs_shot_launch(ctx, map, conf, (uint32_t)ni, dq, maxc, (const PpRsCand*)(d + o_cand),
-                        (const PpRsPair*)(d + o_pair), (PpShotOut*)(d + r_shot));
+      pp_rs_words_launch(ctx, ni, dq, maxc, (PpRsCand*)(dw + o_cand), (PpRsPair*)(dw + o_pair));
+      pp_rs_shot_launch(ctx, map, conf, (uint32_t)ni, dq, maxc, (const PpRsCand*)(dw + o_cand),
+                        (const PpRsPair*)(dw + o_pair), (PpShotOut*)(d + r_shot));
       pp_expand_launch(ctx, map, plan, ni, dq, dq + ni, dq + 2 * ni, (const int64_t*)(d + r_dir),
                        (const double*)(d + r_steer), (const double*)(d + r_cost), (const double*)d_mot, eo);
     }

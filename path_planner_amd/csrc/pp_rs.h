@@ -41,15 +41,14 @@ void pp_rs_words_launch(pp_ctx* ctx, uint64_t n, const double* d_q, double maxc,
 void pp_rs_shot_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, uint32_t n,
                        const double* d_q, double maxc, const PpRsCand* d_cands,
                        const PpRsPair* d_pairs, PpShotOut* d_out, pp_rs_word* d_words = nullptr);
-// A planner round in one launch: the shots of n nodes (k_rs_words must have run) and the nodes'
-// motion primitives side by side.  For rounds of few nodes; large batches use the separate
-// launches, whose shapes suit them.
+// A planner round in one launch: the Reeds-Shepp words and shots of n nodes and the nodes' motion
+// primitives side by side.  For rounds of few nodes; large batches use the separate launches,
+// whose shapes suit them.
 struct PpExpandPlan;
 struct PpExpandDev;
 void pp_round_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, const PpExpandPlan& plan, uint32_t n,
-                     const double* d_q, double maxc, const PpRsCand* d_cands, const PpRsPair* d_pairs,
-                     PpShotOut* d_out, const int64_t* d_pdir, const double* d_psteer, const double* d_pcost,
-                     const double* d_motion, PpExpandDev eo);
+                     const double* d_q, double maxc, PpShotOut* d_out, const int64_t* d_pdir,
+                     const double* d_psteer, const double* d_pcost, const double* d_motion, PpExpandDev eo);
 int32_t pp_rs_single(pp_ctx* ctx, const double q[6], double maxc, double step_size, int only_rank,
                      int32_t* n_paths, pp_rs_word* words, uint64_t* traj_off, double* traj_x,
                      double* traj_y, double* traj_yaw, int64_t* traj_dir, uint64_t traj_cap,

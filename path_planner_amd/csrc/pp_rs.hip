@@ -460,7 +460,7 @@ template <int kShotThreads, int kMaxPaths>
 __device__ __forceinline__ void
 pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, const double* __restrict__ sy,
              const double* __restrict__ syaw, double maxc, double step_size, uint32_t check_step,
-             const PpCostParams& cp, const PpRsCand* __restrict__ cands, const PpRsPair* __restrict__ pairs,
+             const PpCostParams& cp, const PpRsCand* pc /* the pair's 46 candidate slots */, const PpRsPair pr,
              const PpFootprint& f, const PpLattice& lat, const PpBuckets& bk, int use_lattice,
              PpShotOut* __restrict__ out, pp_rs_word* __restrict__ word_out /* optional: the accepted path's word */) {
   __shared__ PathPlan plans[kMaxPaths];
@@ -470,8 +470,6 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
   __shared__ uint32_t n_samples[kMaxPaths + 1];  // sampled poses per path; [kMaxPaths]: their maximum
   __shared__ uint32_t n_settled;
   const int lane = threadIdx.x;
-  const PpRsPair pr = pairs[pair];
-  const PpRsCand* pc = cands + (size_t)pair * PP_RS_MAX_PATHS;
   const int np = pr.n_paths;
   if (np <= np_above || np > kMaxPaths) return;  // uniform over the workgroup
   // path k is the k-th set bit of the accepted mask
@@ -599,13 +597,14 @@ k_rs_shot(uint32_t n, int np_above, const double* __restrict__ sx, const double*
           PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice, PpShotOut* __restrict__ out,
           pp_rs_word* __restrict__ word_out) {
   if (blockIdx.x >= n) return;
-  pp_shot_pair<kShotThreads, kMaxPaths>(blockIdx.x, np_above, sx, sy, syaw, maxc, step_size, check_step, cp, cands,
-                                        pairs, f, lat, bk, use_lattice, out, word_out);
+  pp_shot_pair<kShotThreads, kMaxPaths>(blockIdx.x, np_above, sx, sy, syaw, maxc, step_size, check_step, cp,
+                                        cands + (size_t)blockIdx.x * PP_RS_MAX_PATHS, pairs[blockIdx.x], f, lat, bk,
+                                        use_lattice, out, word_out);
 }
 
-// One launch for a planner round of few nodes: workgroups [0, n) take the nodes' analytic shots,
-// the workgroups behind them the nodes' motion primitives (which do not depend on the shots), so
-// the primitives cost the round no time of their own.
+// One launch for a planner round of few nodes: workgroups [0, n) take the nodes' Reeds-Shepp
+// words and analytic shots, the workgroups behind them the nodes' motion primitives (which do not
+// depend on the shots), so a round is one kernel and the primitives cost it no time of their own.
 struct PpRoundExpand {
   const double *px, *py, *pyaw, *psteer, *pcost, *motion;
   const int64_t* pdir;
@@ -614,20 +613,60 @@ struct PpRoundExpand {
   PpExpandDev out;
 };
 
-__global__ void __launch_bounds__(kShotThreadsFew)
-k_round(uint32_t n, const double* __restrict__ sx, const double* __restrict__ sy,
-        const double* __restrict__ syaw, double maxc, double step_size, uint32_t check_step,
-        PpCostParams cp, const PpRsCand* __restrict__ cands, const PpRsPair* __restrict__ pairs,
-        PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice, PpShotOut* __restrict__ out,
-        PpRoundExpand e) {
+constexpr int kRoundThreads = 512;  // eight waves: seven candidate families side by side
+
+__global__ void __launch_bounds__(kRoundThreads)
+k_round(uint32_t n, const double* __restrict__ q6 /* sx sy syaw gx gy gyaw, n each */, double maxc,
+        double step_size, uint32_t check_step, PpCostParams cp, PpFootprint f, PpLattice lat, PpBuckets bk,
+        int use_lattice, PpShotOut* __restrict__ out, PpRoundExpand e) {
   if (blockIdx.x < n) {
-    pp_shot_pair<kShotThreadsFew, PP_RS_MAX_PATHS>(blockIdx.x, -1, sx, sy, syaw, maxc, step_size, check_step, cp,
-                                                   cands, pairs, f, lat, bk, use_lattice, out, nullptr);
+    // the pair's words first (k_rs_words for one pair: a wave per family, its first lane working),
+    // kept in LDS for the shot that follows
+    __shared__ PpRsCand s_cands[PP_RS_MAX_PATHS];
+    __shared__ unsigned long long s_acc[kRsFamilies];
+    __shared__ uint32_t s_fl[kRsFamilies];
+    __shared__ PpRsPair s_pair;
+    const uint32_t i = blockIdx.x, fam = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0u && fam < (uint32_t)kRsFamilies) {
+      const PpRsInput in = pp_rs_input(q6[i], q6[n + i], q6[2 * (size_t)n + i], q6[3 * (size_t)n + i],
+                                       q6[4 * (size_t)n + i], q6[5 * (size_t)n + i], maxc);
+      PpRsState S;
+      AllSink sink{s_cands};
+      switch (fam) {  // wave-uniform
+        case 0: pp_rs_family<0>(in, S, sink); break;
+        case 1: pp_rs_family<1>(in, S, sink); break;
+        case 2: pp_rs_family<2>(in, S, sink); break;
+        case 3: pp_rs_family<3>(in, S, sink); break;
+        case 4: pp_rs_family<4>(in, S, sink); break;
+        case 5: pp_rs_family<5>(in, S, sink); break;
+        default: pp_rs_family<6>(in, S, sink); break;
+      }
+      s_acc[fam] = S.accepted;
+      s_fl[fam] = (S.degenerate ? 4u : 0u) | (S.A.amb ? 2u : 0u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long a = 0;
+      uint32_t fl = 0;
+#pragma unroll
+      for (int k = 0; k < kRsFamilies; ++k) {
+        a |= s_acc[k];
+        fl |= s_fl[k];
+      }
+      PpRsPair p;
+      p.accepted = (fl & 4u) ? 0ull : a;
+      p.flags = fl;
+      p.n_paths = __popcll(p.accepted);
+      s_pair = p;
+    }
+    __syncthreads();
+    pp_shot_pair<kRoundThreads, PP_RS_MAX_PATHS>(i, -1, q6, q6 + n, q6 + 2 * (size_t)n, maxc, step_size, check_step,
+                                                 cp, s_cands, s_pair, f, lat, bk, use_lattice, out, nullptr);
     return;
   }
   const uint64_t items = (uint64_t)n * e.n_prim;
-  const uint64_t stride = (uint64_t)(gridDim.x - n) * kShotThreadsFew;
-  for (uint64_t t = (uint64_t)(blockIdx.x - n) * kShotThreadsFew + threadIdx.x; t < items; t += stride)
+  const uint64_t stride = (uint64_t)(gridDim.x - n) * kRoundThreads;
+  for (uint64_t t = (uint64_t)(blockIdx.x - n) * kRoundThreads + threadIdx.x; t < items; t += stride)
     pp_expand_item(t, e.n_prim, e.px, e.py, e.pyaw, e.pdir, e.psteer, e.pcost, e.motion, e.prm, f, lat, bk,
                    use_lattice, nullptr, e.out);
 }
@@ -803,9 +842,8 @@ void pp_rs_shot_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, ui
 }
 
 void pp_round_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, const PpExpandPlan& plan, uint32_t n,
-                     const double* d_q, double maxc, const PpRsCand* d_cands, const PpRsPair* d_pairs,
-                     PpShotOut* d_out, const int64_t* d_pdir, const double* d_psteer, const double* d_pcost,
-                     const double* d_motion, PpExpandDev eo) {
+                     const double* d_q, double maxc, PpShotOut* d_out, const int64_t* d_pdir,
+                     const double* d_psteer, const double* d_pcost, const double* d_motion, PpExpandDev eo) {
   if (n == 0) return;
   PpFootprint f = pp_make_footprint(conf);
   uint32_t cs = (uint32_t)std::min<uint64_t>(conf->collision_check_step, 0x7fffffffu);
@@ -821,10 +859,9 @@ void pp_round_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, cons
   e.prm = plan.prm;
   e.out = eo;
   const uint64_t items = (uint64_t)n * plan.n_prim;
-  const unsigned eb = (unsigned)((items + kShotThreadsFew - 1) / kShotThreadsFew);
-  hipLaunchKernelGGL(k_round, dim3(n + eb), dim3(kShotThreadsFew), 0, ctx->stream, n, d_q, d_q + n,
-                     d_q + 2 * (size_t)n, maxc, conf->move_step, cs, cost_params(conf), d_cands, d_pairs, f, map->lat,
-                     map->bk, map->lattice ? 1 : 0, d_out, e);
+  const unsigned eb = (unsigned)((items + kRoundThreads - 1) / kRoundThreads);
+  hipLaunchKernelGGL(k_round, dim3(n + eb), dim3(kRoundThreads), 0, ctx->stream, n, d_q, maxc, conf->move_step, cs,
+                     cost_params(conf), f, map->lat, map->bk, map->lattice ? 1 : 0, d_out, e);
 }
 
 extern "C" int32_t pp_rs_batch_dev(pp_ctx* ctx, uint64_t n, const double* d_sx, const double* d_sy,

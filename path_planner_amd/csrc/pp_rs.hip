@@ -613,43 +613,48 @@ struct PpRoundExpand {
   PpExpandDev out;
 };
 
-constexpr int kRoundThreads = 512;  // eight waves: seven candidate families side by side
+constexpr int kRoundThreads = 1024;  // sixteen waves: the twelve candidate groups side by side
 
 __global__ void __launch_bounds__(kRoundThreads)
 k_round(uint32_t n, const double* __restrict__ q6 /* sx sy syaw gx gy gyaw, n each */, double maxc,
         double step_size, uint32_t check_step, PpCostParams cp, PpFootprint f, PpLattice lat, PpBuckets bk,
         int use_lattice, PpShotOut* __restrict__ out, PpRoundExpand e) {
   if (blockIdx.x < n) {
-    // the pair's words first (k_rs_words for one pair: a wave per family, its first lane working),
-    // kept in LDS for the shot that follows
+    // the pair's words first (k_rs_words for one pair, a wave per group of at most four candidates,
+    // its first lane working), kept in LDS for the shot that follows
     __shared__ PpRsCand s_cands[PP_RS_MAX_PATHS];
-    __shared__ unsigned long long s_acc[kRsFamilies];
-    __shared__ uint32_t s_fl[kRsFamilies];
+    __shared__ unsigned long long s_acc[kRsGroups];
+    __shared__ uint32_t s_fl[kRsGroups];
     __shared__ PpRsPair s_pair;
-    const uint32_t i = blockIdx.x, fam = threadIdx.x >> 6;
-    if ((threadIdx.x & 63u) == 0u && fam < (uint32_t)kRsFamilies) {
+    const uint32_t i = blockIdx.x, grp = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0u && grp < (uint32_t)kRsGroups) {
       const PpRsInput in = pp_rs_input(q6[i], q6[n + i], q6[2 * (size_t)n + i], q6[3 * (size_t)n + i],
                                        q6[4 * (size_t)n + i], q6[5 * (size_t)n + i], maxc);
       PpRsState S;
       AllSink sink{s_cands};
-      switch (fam) {  // wave-uniform
-        case 0: pp_rs_family<0>(in, S, sink); break;
-        case 1: pp_rs_family<1>(in, S, sink); break;
-        case 2: pp_rs_family<2>(in, S, sink); break;
-        case 3: pp_rs_family<3>(in, S, sink); break;
-        case 4: pp_rs_family<4>(in, S, sink); break;
-        case 5: pp_rs_family<5>(in, S, sink); break;
-        default: pp_rs_family<6>(in, S, sink); break;
+      switch (grp) {  // wave-uniform
+        case 0: pp_rs_group<0>(in, S, sink); break;
+        case 1: pp_rs_group<1>(in, S, sink); break;
+        case 2: pp_rs_group<2>(in, S, sink); break;
+        case 3: pp_rs_group<3>(in, S, sink); break;
+        case 4: pp_rs_group<4>(in, S, sink); break;
+        case 5: pp_rs_group<5>(in, S, sink); break;
+        case 6: pp_rs_group<6>(in, S, sink); break;
+        case 7: pp_rs_group<7>(in, S, sink); break;
+        case 8: pp_rs_group<8>(in, S, sink); break;
+        case 9: pp_rs_group<9>(in, S, sink); break;
+        case 10: pp_rs_group<10>(in, S, sink); break;
+        default: pp_rs_group<11>(in, S, sink); break;
       }
-      s_acc[fam] = S.accepted;
-      s_fl[fam] = (S.degenerate ? 4u : 0u) | (S.A.amb ? 2u : 0u);
+      s_acc[grp] = S.accepted;
+      s_fl[grp] = (S.degenerate ? 4u : 0u) | (S.A.amb ? 2u : 0u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
       unsigned long long a = 0;
       uint32_t fl = 0;
 #pragma unroll
-      for (int k = 0; k < kRsFamilies; ++k) {
+      for (int k = 0; k < kRsGroups; ++k) {
         a |= s_acc[k];
         fl |= s_fl[k];
       }

@@ -336,58 +336,102 @@ __device__ __forceinline__ PpRsInput pp_rs_input(double sx, double sy, double sy
   return in;
 }
 
-// The 46 candidates fall into seven groups whose duplicate tests (set_path compares only paths
-// with identical letters) never look outside the group, so the groups can be evaluated in any
-// order, or by different waves, and still accept exactly the reference's paths.
+// The 46 candidates fall into seven families whose duplicate tests (set_path compares only paths
+// with identical letters) never look outside the family, so the families can be evaluated in any
+// order, or by different waves, and still accept exactly the reference's paths.  Inside a family
+// the same holds for the words: twelve groups of at most four candidates, each group a set of
+// words no other group shares.
 constexpr int kRsFamilies = 7;
+constexpr int kRsGroups = 12;
 
-template <int FAM, class Sink>
-__device__ __forceinline__ void pp_rs_family(const PpRsInput& in, PpRsState& S, Sink& sink) {
-  if constexpr (FAM == 0) {  // scs :202-211 -- generation indices 0, 1
+template <int G, class Sink>
+__device__ __forceinline__ void pp_rs_group(const PpRsInput& in, PpRsState& S, Sink& sink) {
+  if constexpr (G == 0) {  // scs :202-211 -- generation indices 0, 1
     PpWordSet<3> a, b;
     pp_candidate<PP_F_SLS_, 0, false, PP_TUV, 3>(S, in, a, 0, pp_word("SLS"), sink);
     pp_candidate<PP_F_SLS_, 2, false, PP_TUV, 3>(S, in, b, 1, pp_word("SLS"), sink);
   }
-  if constexpr (FAM == 1) {  // csc :231-270 -- 2..9
-    PpWordSet<3> a, b, c, d;
+  if constexpr (G == 1) {  // csc :231-270 -- 2..5
+    PpWordSet<3> a, b;
     pp_pair<PP_F_LSL_, 0, false, PP_TUV, 3>(S, in, a, 2, pp_word("LSL"), sink);
     pp_pair<PP_F_LSL_, 2, false, PP_TUV, 3>(S, in, b, 2, pp_word("LSL"), sink);
+  }
+  if constexpr (G == 2) {  // csc -- 6..9
+    PpWordSet<3> c, d;
     pp_pair<PP_F_LSR_, 0, false, PP_TUV, 3>(S, in, c, 6, pp_word("LSR"), sink);
     pp_pair<PP_F_LSR_, 2, false, PP_TUV, 3>(S, in, d, 6, pp_word("LSR"), sink);
   }
-  if constexpr (FAM == 2) {  // ccc :272-316 -- 10..17; LRL / RLR each collect four candidates
-    PpWordSet<3> a, b;
+  if constexpr (G == 3) {  // ccc :272-316 -- LRL collects four candidates (10, 11, 14, 15)
+    PpWordSet<3> a;
     pp_pair<PP_F_LRL_, 0, false, PP_TUV, 3>(S, in, a, 10, pp_word("LRL"), sink);
     pp_pair<PP_F_LRL_, 0, true, PP_VUT, 3>(S, in, a, 14, pp_word("LRL"), sink);
+  }
+  if constexpr (G == 4) {  // ccc -- RLR (12, 13, 16, 17)
+    PpWordSet<3> b;
     pp_pair<PP_F_LRL_, 2, false, PP_TUV, 3>(S, in, b, 10, pp_word("LRL"), sink);
     pp_pair<PP_F_LRL_, 2, true, PP_VUT, 3>(S, in, b, 14, pp_word("LRL"), sink);
   }
-  if constexpr (FAM == 3) {  // cccc :366-406 -- 18..25
-    PpWordSet<4> a, b;
+  if constexpr (G == 5) {  // cccc :366-406 -- LRLR (18, 19, 22, 23)
+    PpWordSet<4> a;
     pp_pair<PP_F_LRLRN_, 0, false, PP_T_U_NU_V, 4>(S, in, a, 18, pp_word("LRLR"), sink);
     pp_pair<PP_F_LRLRP_, 0, false, PP_T_U_U_V, 4>(S, in, a, 22, pp_word("LRLR"), sink);
+  }
+  if constexpr (G == 6) {  // cccc -- RLRL (20, 21, 24, 25)
+    PpWordSet<4> b;
     pp_pair<PP_F_LRLRN_, 2, false, PP_T_U_NU_V, 4>(S, in, b, 18, pp_word("LRLR"), sink);
     pp_pair<PP_F_LRLRP_, 2, false, PP_T_U_U_V, 4>(S, in, b, 22, pp_word("LRLR"), sink);
   }
-  if constexpr (FAM == 4) {  // ccsc :440-524 -- 26..33
-    PpWordSet<4> a, b, c, d;
+  if constexpr (G == 7) {  // ccsc :440-524 -- 26..29
+    PpWordSet<4> a, b;
     pp_pair<PP_F_LRSL_, 0, false, PP_T_H_U_V, 4>(S, in, a, 26, pp_word("LRSL"), sink);
     pp_pair<PP_F_LRSL_, 2, false, PP_T_H_U_V, 4>(S, in, b, 26, pp_word("LRSL"), sink);
+  }
+  if constexpr (G == 8) {  // ccsc -- 30..33
+    PpWordSet<4> c, d;
     pp_pair<PP_F_LRSR_, 0, false, PP_T_H_U_V, 4>(S, in, c, 30, pp_word("LRSR"), sink);
     pp_pair<PP_F_LRSR_, 2, false, PP_T_H_U_V, 4>(S, in, d, 30, pp_word("LRSR"), sink);
   }
-  if constexpr (FAM == 5) {  // ccsc, backwards -- 34..41
-    PpWordSet<4> a, b, c, d;
+  if constexpr (G == 9) {  // ccsc, backwards -- 34..37
+    PpWordSet<4> a, b;
     pp_pair<PP_F_LRSL_, 0, true, PP_V_U_H_T, 4>(S, in, a, 34, pp_word("LSRL"), sink);
     pp_pair<PP_F_LRSL_, 2, true, PP_V_U_H_T, 4>(S, in, b, 34, pp_word("LSRL"), sink);
+  }
+  if constexpr (G == 10) {  // ccsc, backwards -- 38..41
+    PpWordSet<4> c, d;
     pp_pair<PP_F_LRSR_, 0, true, PP_V_U_H_T, 4>(S, in, c, 38, pp_word("RSRL"), sink);
     pp_pair<PP_F_LRSR_, 2, true, PP_V_U_H_T, 4>(S, in, d, 38, pp_word("RSRL"), sink);
   }
-  if constexpr (FAM == 6) {  // ccscc :544-580 -- 42..45
+  if constexpr (G == 11) {  // ccscc :544-580 -- 42..45
     PpWordSet<5> a, b;
     pp_pair<PP_F_LRSLR_, 0, false, PP_T_H_U_H_V, 5>(S, in, a, 42, pp_word("LRSLR"), sink);
     pp_pair<PP_F_LRSLR_, 2, false, PP_T_H_U_H_V, 5>(S, in, b, 42, pp_word("LRSLR"), sink);
   }
+}
+
+template <int FAM, class Sink>
+__device__ __forceinline__ void pp_rs_family(const PpRsInput& in, PpRsState& S, Sink& sink) {
+  if constexpr (FAM == 0) pp_rs_group<0>(in, S, sink);
+  if constexpr (FAM == 1) {
+    pp_rs_group<1>(in, S, sink);
+    pp_rs_group<2>(in, S, sink);
+  }
+  if constexpr (FAM == 2) {
+    pp_rs_group<3>(in, S, sink);
+    pp_rs_group<4>(in, S, sink);
+  }
+  if constexpr (FAM == 3) {
+    pp_rs_group<5>(in, S, sink);
+    pp_rs_group<6>(in, S, sink);
+  }
+  if constexpr (FAM == 4) {
+    pp_rs_group<7>(in, S, sink);
+    pp_rs_group<8>(in, S, sink);
+  }
+  if constexpr (FAM == 5) {
+    pp_rs_group<9>(in, S, sink);
+    pp_rs_group<10>(in, S, sink);
+  }
+  if constexpr (FAM == 6) pp_rs_group<11>(in, S, sink);
 }
 
 // generate_path, :707-725: the families in the reference's order.

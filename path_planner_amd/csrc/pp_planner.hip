@@ -840,14 +840,17 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     uint32_t nroll, roll0;       // rollout lists used, first one's index in the batch
   };
   std::vector<Found> found;
-  std::vector<double> in5;
   for (uint64_t i = 0; i < nq; ++i) {
-    Query& q = Q[i];
     out[i].len = 0;
     out[i].cost = 0.0;
-    if (!q.found) continue;
+    if (!Q[i].found) continue;
     Found f;
     f.q = (uint32_t)i;
+    found.push_back(std::move(f));
+  }
+  pool.run(found.size(), [&](size_t k) {
+    Found& f = found[k];
+    const Query& q = Q[f.q];
     for (int32_t id = q.final_parent; id >= 0; id = q.nodes[id].parent) f.chain.push_back(id);
     const SNode& fp = q.nodes[q.final_parent];
     // The reference walks `while node.pind >= 0` with pind an isize copy of the parent's key
@@ -857,14 +860,27 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     f.nroll = 0;
     if (f.with_final)
       while (f.nroll + 1 < f.chain.size() && q.nodes[f.chain[f.nroll]].pind >= 0) ++f.nroll;
-    f.roll0 = (uint32_t)(in5.size() / 5);
-    for (uint32_t k = 0; k < f.nroll; ++k) {
-      const SNode& n = q.nodes[f.chain[k]];
-      const SNode& pa = q.nodes[n.parent];
-      in5.insert(in5.end(), {pa.x, pa.y, pa.yaw, n.steer, plan.motion[NP + n.prim]});
-    }
-    found.push_back(std::move(f));
+  });
+  uint32_t nroll_sum = 0;
+  for (Found& f : found) {
+    f.roll0 = nroll_sum;
+    nroll_sum += f.nroll;
   }
+  std::vector<double> in5((size_t)nroll_sum * 5);
+  pool.run(found.size(), [&](size_t k) {
+    const Found& f = found[k];
+    const Query& q = Q[f.q];
+    for (uint32_t r = 0; r < f.nroll; ++r) {
+      const SNode& n = q.nodes[f.chain[r]];
+      const SNode& pa = q.nodes[n.parent];
+      double* o = in5.data() + (size_t)(f.roll0 + r) * 5;
+      o[0] = pa.x;
+      o[1] = pa.y;
+      o[2] = pa.yaw;
+      o[3] = n.steer;
+      o[4] = plan.motion[NP + n.prim];
+    }
+  });
   const double x0 = now_ms();
   const uint32_t nf = (uint32_t)found.size();
   const uint32_t pts = plan.prm.nlist + 1;

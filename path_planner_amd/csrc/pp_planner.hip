@@ -193,7 +193,11 @@ inline uint64_t calc_index(uint64_t xind, uint64_t yind, int64_t yawind, const p
   return (uint64_t)(yawind - P.minyaw) * P.xw * P.yw + (yind - P.miny) * P.xw + (xind - P.minx);
 }
 
-// A small fork-join pool: run(n, fn) calls fn(i) for i in [0, n) on the workers and the caller.
+// Fork-join pool for the per-query host work of a round: run(n, fn) calls fn(i) for i in [0, n) on
+// the workers and the caller.  A round is short and the next one follows
+// within a few hundred microseconds, so a worker spins on the job counter for a while before it
+// goes to sleep on the condition variable (waking a sleeper costs more than a small round's work),
+// and the caller spins the same way for the workers to finish.
 class Pool {
  public:
   explicit Pool(unsigned workers) {
@@ -202,7 +206,7 @@ class Pool {
   ~Pool() {
     {
       std::lock_guard<std::mutex> l(m_);
-      stop_ = true;
+      stop_.store(true, std::memory_order_release);
     }
     cv_.notify_all();
     for (auto& t : th_) t.join();
@@ -213,22 +217,37 @@ class Pool {
       for (size_t i = 0; i < n; ++i) fn(i);
       return;
     }
+    fn_ = &fn;
+    n_ = n;
+    next_.store(0, std::memory_order_relaxed);
+    pending_.store(th_.size(), std::memory_order_relaxed);
     {
-      std::lock_guard<std::mutex> l(m_);
-      fn_ = &fn;
-      n_ = n;
-      next_.store(0);
-      pending_ = th_.size();
-      ++gen_;
+      std::lock_guard<std::mutex> l(m_);  // a worker between its predicate check and its sleep holds m_
+      gen_.fetch_add(1, std::memory_order_release);
     }
     cv_.notify_all();
     work();
-    std::unique_lock<std::mutex> l(m_);
-    done_.wait(l, [this] { return pending_ == 0; });
+    if (!spin_until([this] { return pending_.load(std::memory_order_acquire) == 0; })) {
+      std::unique_lock<std::mutex> l(m_);
+      done_.wait(l, [this] { return pending_.load(std::memory_order_acquire) == 0; });
+    }
     fn_ = nullptr;
   }
 
  private:
+  static constexpr double kSpinMs = 0.3;
+  template <class Pred>
+  static bool spin_until(Pred&& p) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      for (int k = 0; k < 64; ++k) {
+        if (p()) return true;
+        __builtin_ia32_pause();
+      }
+      if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > kSpinMs)
+        return p();
+    }
+  }
   void work() {
     for (;;) {
       size_t i = next_.fetch_add(16);
@@ -240,16 +259,19 @@ class Pool {
   void loop() {
     uint64_t seen = 0;
     for (;;) {
-      {
+      auto news = [&] {
+        return stop_.load(std::memory_order_acquire) || gen_.load(std::memory_order_acquire) != seen;
+      };
+      if (!spin_until(news)) {
         std::unique_lock<std::mutex> l(m_);
-        cv_.wait(l, [&] { return stop_ || gen_ != seen; });
-        if (stop_) return;
-        seen = gen_;
+        cv_.wait(l, news);
       }
+      if (stop_.load(std::memory_order_acquire)) return;
+      seen = gen_.load(std::memory_order_acquire);
       work();
-      {
+      if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
         std::lock_guard<std::mutex> l(m_);
-        if (--pending_ == 0) done_.notify_one();
+        done_.notify_one();
       }
     }
   }
@@ -259,9 +281,9 @@ class Pool {
   const std::function<void(size_t)>* fn_ = nullptr;
   size_t n_ = 0;
   std::atomic<size_t> next_{0};
-  size_t pending_ = 0;
-  uint64_t gen_ = 0;
-  bool stop_ = false;
+  std::atomic<size_t> pending_{0};
+  std::atomic<uint64_t> gen_{0};
+  std::atomic<bool> stop_{false};
 };
 
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }

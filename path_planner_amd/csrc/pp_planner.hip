@@ -746,8 +746,8 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     double* hsteer = (double*)(h + r_steer);
     double* hcost = (double*)(h + r_cost);
     int32_t* hhid = (int32_t*)(h + r_hid);
-    for (uint32_t id : live_ids) {
-      const Query& q = Q[id];
+    pool.run(nl, [&](size_t li) {  // every query fills its own slots
+      const Query& q = Q[live_ids[li]];
       for (size_t j = 0; j < q.want.size(); ++j) {
         const SNode& n = q.nodes[q.want[j]];
         const size_t k = q.item0 + j;
@@ -762,7 +762,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         hcost[k] = n.cost;
         hhid[k] = q.hmap_slot;
       }
-    }
+    });
     const double p2 = prof ? now_ms() : 0.0;
     if (prof) {
       p_stage[pc] += p2 - p1;

@@ -11,6 +11,17 @@
 #include "pp_rs_device.h"
 #include "pp_expand_device.h"
 
+#ifdef PP_LAB_STAMPS
+__device__ long long lab_stamp[16];
+#define PP_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) lab_stamp[k] = wall_clock64(); } while (0)
+extern "C" int32_t pp_lab_stamps(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lab_stamp), sizeof(lab_stamp)) == hipSuccess ? 0 : -1;
+}
+__device__ inline void lab_stamp_end() { lab_stamp[7] = wall_clock64(); }
+#else
+#define PP_STAMP(k) do {} while (0)
+__device__ inline void lab_stamp_end() {}
+#endif
 namespace {
 
 // ------------------------------------------------------------------ K3: words, one lane per pair
@@ -476,6 +487,7 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
   if (lane < 64 && ((pr.accepted >> lane) & 1ull))
     gen_of[__builtin_popcountll(pr.accepted & ((1ull << lane) - 1ull))] = (uint8_t)lane;
   __syncthreads();
+  PP_STAMP(3);
   const double step = step_size * maxc;
   // the paths live on the first np lanes of wave 0 (np <= 46) from here to the end
   for (int t = lane; t < np * 5; t += kShotThreads) {
@@ -484,6 +496,7 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
     if (i < c.nseg) plan_segment(c, i, maxc, plans[p].seg[i]);
   }
   __syncthreads();
+  PP_STAMP(4);
   uint32_t my_tasks = 0;
   if (lane < np) {
     const PpRsCand c = pc[gen_of[lane]];
@@ -507,6 +520,7 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
     }
   }
   __syncthreads();
+  PP_STAMP(5);
   // Tasks in pose-major order: slot t is sample t / np of path t % np (slots past a path's last
   // sample are empty), so the early samples of every path come first.  is_collision returns at a
   // path's first colliding pose, and a path with a clear hit is settled whatever its other poses
@@ -532,6 +546,7 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
     }
   }
   __syncthreads();
+  PP_STAMP(6);
   if (lane >= 64) return;
   // Pop order of BinaryHeap<(Reverse(cost), i)>: cost ascending, ties -> larger i.  Each lane ranks
   // its own path; the accepted path is the collision-free one of lowest rank, and the paths popped
@@ -578,6 +593,7 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
       o.flags |= 1u;
     }
     out[pair] = o;
+    if (blockIdx.x == 0) lab_stamp_end();
     if (word_out) {
       pp_rs_word wz{};
       if (o.path_idx >= 0) {
@@ -619,52 +635,46 @@ __global__ void __launch_bounds__(kRoundThreads)
 k_round(uint32_t n, const double* __restrict__ q6 /* sx sy syaw gx gy gyaw, n each */, double maxc,
         double step_size, uint32_t check_step, PpCostParams cp, PpFootprint f, PpLattice lat, PpBuckets bk,
         int use_lattice, PpShotOut* __restrict__ out, PpRoundExpand e) {
+  PP_STAMP(0);
   if (blockIdx.x < n) {
-    // the pair's words first (k_rs_words for one pair, a wave per group of at most four candidates,
-    // its first lane working), kept in LDS for the shot that follows
+    // The pair's words first: wave g < 12 evaluates formula g, its lanes 0..3 the four mirror
+    // images; then lane s < 20 of wave 0 runs set_path's duplicate test over the candidates of
+    // word s in the reference's order.  Candidates and the pair record stay in LDS for the shot.
     __shared__ PpRsCand s_cands[PP_RS_MAX_PATHS];
-    __shared__ unsigned long long s_acc[kRsGroups];
-    __shared__ uint32_t s_fl[kRsGroups];
+    __shared__ PpRsRaw s_raw[PP_RS_MAX_PATHS];
+    __shared__ unsigned long long s_acc;
+    __shared__ uint32_t s_fl;
     __shared__ PpRsPair s_pair;
-    const uint32_t i = blockIdx.x, grp = threadIdx.x >> 6;
-    if ((threadIdx.x & 63u) == 0u && grp < (uint32_t)kRsGroups) {
+    const uint32_t i = blockIdx.x, wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
+    if (threadIdx.x == 0) {
+      s_acc = 0ull;
+      s_fl = 0u;
+    }
+    if (wave < 12u && wl < 4u) {
       const PpRsInput in = pp_rs_input(q6[i], q6[n + i], q6[2 * (size_t)n + i], q6[3 * (size_t)n + i],
                                        q6[4 * (size_t)n + i], q6[5 * (size_t)n + i], maxc);
-      PpRsState S;
-      AllSink sink{s_cands};
-      switch (grp) {  // wave-uniform
-        case 0: pp_rs_group<0>(in, S, sink); break;
-        case 1: pp_rs_group<1>(in, S, sink); break;
-        case 2: pp_rs_group<2>(in, S, sink); break;
-        case 3: pp_rs_group<3>(in, S, sink); break;
-        case 4: pp_rs_group<4>(in, S, sink); break;
-        case 5: pp_rs_group<5>(in, S, sink); break;
-        case 6: pp_rs_group<6>(in, S, sink); break;
-        case 7: pp_rs_group<7>(in, S, sink); break;
-        case 8: pp_rs_group<8>(in, S, sink); break;
-        case 9: pp_rs_group<9>(in, S, sink); break;
-        case 10: pp_rs_group<10>(in, S, sink); break;
-        default: pp_rs_group<11>(in, S, sink); break;
-      }
-      s_acc[grp] = S.accepted;
-      s_fl[grp] = (S.degenerate ? 4u : 0u) | (S.A.amb ? 2u : 0u);
+      PpAmb A{false};
+      pp_rs_eval_wave(in, (int)wave, (int)wl, A, s_raw);
+      if (A.amb) atomicOr(&s_fl, 2u);
+    }
+    __syncthreads();
+    PP_STAMP(1);
+    if (threadIdx.x < (uint32_t)kRsWordSets) {
+      uint32_t fl = 0;
+      const unsigned long long acc = pp_rs_commit_set((int)threadIdx.x, s_raw, s_cands, &fl);
+      if (acc) atomicOr(&s_acc, acc);
+      if (fl) atomicOr(&s_fl, fl);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      unsigned long long a = 0;
-      uint32_t fl = 0;
-#pragma unroll
-      for (int k = 0; k < kRsGroups; ++k) {
-        a |= s_acc[k];
-        fl |= s_fl[k];
-      }
       PpRsPair p;
-      p.accepted = (fl & 4u) ? 0ull : a;
-      p.flags = fl;
+      p.accepted = (s_fl & 4u) ? 0ull : s_acc;
+      p.flags = s_fl;
       p.n_paths = __popcll(p.accepted);
       s_pair = p;
     }
     __syncthreads();
+    PP_STAMP(2);
     pp_shot_pair<kRoundThreads, PP_RS_MAX_PATHS>(i, -1, q6, q6 + n, q6 + 2 * (size_t)n, maxc, step_size, check_step,
                                                  cp, s_cands, s_pair, f, lat, bk, use_lattice, out, nullptr);
     return;

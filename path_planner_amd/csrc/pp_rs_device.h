@@ -434,6 +434,122 @@ __device__ __forceinline__ void pp_rs_family(const PpRsInput& in, PpRsState& S, 
   if constexpr (FAM == 6) pp_rs_group<11>(in, S, sink);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same 46 candidates for ONE pair spread over the lanes of a workgroup: the four mirror images
+// of a formula differ only in the signs of its inputs and outputs, so lanes 0..3 of a wave evaluate
+// them in one pass over the formula's code (twelve waves, one per formula and direction), and
+// set_path's order-dependent duplicate test then runs per word over the stored results.
+
+struct PpRsRaw {       // one evaluated candidate, indexed by generation index
+  double len[5];
+  uint32_t word;
+  int32_t nseg;        // 0: the formula rejected the candidate
+};
+
+// Formula F on mirror image K (a run-time value here) of the forward or backward point.
+template <int F, bool BACK, int LAY, int N>
+__device__ __forceinline__ void pp_eval_image(const PpRsInput& in, int K, uint32_t word_k0, PpAmb& A,
+                                              PpRsRaw& out) {
+  const double bx = BACK ? in.xb : in.x, by = BACK ? in.yb : in.y;
+  const double ax = (K & 1) ? -bx : bx;
+  const double ay = (K & 2) ? -by : by;
+  const bool negphi = (K == 1 || K == 2);
+  const double ap = negphi ? -in.phi : in.phi;
+  const double sp = negphi ? -in.sp : in.sp;
+  const PpTuv r = pp_eval<F>(ax, ay, ap, sp, in.cp, A);
+  out.nseg = 0;
+  if (!r.ok) return;
+  const double H = 0.5 * PP_RS_PI;
+  double len[5] = {0, 0, 0, 0, 0};
+  if constexpr (LAY == PP_TUV) { len[0] = r.t; len[1] = r.u; len[2] = r.v; }
+  if constexpr (LAY == PP_VUT) { len[0] = r.v; len[1] = r.u; len[2] = r.t; }
+  if constexpr (LAY == PP_T_U_NU_V) { len[0] = r.t; len[1] = r.u; len[2] = -r.u; len[3] = r.v; }
+  if constexpr (LAY == PP_T_U_U_V) { len[0] = r.t; len[1] = r.u; len[2] = r.u; len[3] = r.v; }
+  if constexpr (LAY == PP_T_H_U_V) { len[0] = r.t; len[1] = -H; len[2] = r.u; len[3] = r.v; }
+  if constexpr (LAY == PP_V_U_H_T) { len[0] = r.v; len[1] = r.u; len[2] = -H; len[3] = r.t; }
+  if constexpr (LAY == PP_T_H_U_H_V) { len[0] = r.t; len[1] = -H; len[2] = r.u; len[3] = -H; len[4] = r.v; }
+#pragma unroll
+  for (int i = 0; i < N; ++i) out.len[i] = (K & 1) ? -len[i] : len[i];
+#pragma unroll
+  for (int i = N; i < 5; ++i) out.len[i] = 0.0;
+  out.word = (K & 2) ? pp_word_reflect(word_k0) : word_k0;
+  out.nseg = N;
+}
+
+// Wave `g` (0..11) of the workgroup evaluates its formula; lane = mirror image.  raw[] has 46 slots.
+__device__ __forceinline__ void pp_rs_eval_wave(const PpRsInput& in, int g, int lane, PpAmb& A, PpRsRaw* raw) {
+  if (g == 0) {  // scs :202-211: images 0 and 2 only
+    if (lane < 2) pp_eval_image<PP_F_SLS_, false, PP_TUV, 3>(in, 2 * lane, pp_word("SLS"), A, raw[lane]);
+    return;
+  }
+  if (lane >= 4) return;
+  switch (g) {
+    case 1: pp_eval_image<PP_F_LSL_, false, PP_TUV, 3>(in, lane, pp_word("LSL"), A, raw[2 + lane]); break;
+    case 2: pp_eval_image<PP_F_LSR_, false, PP_TUV, 3>(in, lane, pp_word("LSR"), A, raw[6 + lane]); break;
+    case 3: pp_eval_image<PP_F_LRL_, false, PP_TUV, 3>(in, lane, pp_word("LRL"), A, raw[10 + lane]); break;
+    case 4: pp_eval_image<PP_F_LRL_, true, PP_VUT, 3>(in, lane, pp_word("LRL"), A, raw[14 + lane]); break;
+    case 5: pp_eval_image<PP_F_LRLRN_, false, PP_T_U_NU_V, 4>(in, lane, pp_word("LRLR"), A, raw[18 + lane]); break;
+    case 6: pp_eval_image<PP_F_LRLRP_, false, PP_T_U_U_V, 4>(in, lane, pp_word("LRLR"), A, raw[22 + lane]); break;
+    case 7: pp_eval_image<PP_F_LRSL_, false, PP_T_H_U_V, 4>(in, lane, pp_word("LRSL"), A, raw[26 + lane]); break;
+    case 8: pp_eval_image<PP_F_LRSR_, false, PP_T_H_U_V, 4>(in, lane, pp_word("LRSR"), A, raw[30 + lane]); break;
+    case 9: pp_eval_image<PP_F_LRSL_, true, PP_V_U_H_T, 4>(in, lane, pp_word("LSRL"), A, raw[34 + lane]); break;
+    case 10: pp_eval_image<PP_F_LRSR_, true, PP_V_U_H_T, 4>(in, lane, pp_word("RSRL"), A, raw[38 + lane]); break;
+    default: pp_eval_image<PP_F_LRSLR_, false, PP_T_H_U_H_V, 5>(in, lane, pp_word("LRSLR"), A, raw[42 + lane]); break;
+  }
+}
+
+// The twenty words and the generation indices offered to each, in the reference's order (-1 ends).
+constexpr int kRsWordSets = 20;
+__device__ constexpr int8_t kRsWordSetGens[kRsWordSets][4] = {
+    {0, -1, -1, -1},    {1, -1, -1, -1},                                            // scs
+    {2, 3, -1, -1},     {4, 5, -1, -1},     {6, 7, -1, -1},     {8, 9, -1, -1},     // csc
+    {10, 11, 14, 15},   {12, 13, 16, 17},                                           // ccc
+    {18, 19, 22, 23},   {20, 21, 24, 25},                                           // cccc
+    {26, 27, -1, -1},   {28, 29, -1, -1},   {30, 31, -1, -1},   {32, 33, -1, -1},   // ccsc
+    {34, 35, -1, -1},   {36, 37, -1, -1},   {38, 39, -1, -1},   {40, 41, -1, -1},   // ccsc, backwards
+    {42, 43, -1, -1},   {44, 45, -1, -1}};                                          // ccscc
+
+// set_path (:130-159) for word set `ws` over the stored candidates; the accepted ones go to
+// slots[gen].  Returns the accepted bits; *flags gets bit 2 (degenerate) and bit 1 (guard band).
+__device__ __forceinline__ unsigned long long pp_rs_commit_set(int ws, const PpRsRaw* raw, PpRsCand* slots,
+                                                               uint32_t* flags) {
+  PpAmb A{false};
+  unsigned long long acc = 0;
+  bool degenerate = false;
+  int kept[4], nk = 0;
+  for (int c = 0; c < 4; ++c) {
+    const int gen = kRsWordSetGens[ws][c];
+    if (gen < 0) break;
+    const PpRsRaw& r = raw[gen];
+    const int N = r.nseg;
+    if (N == 0) continue;
+    bool dup = false;
+    for (int e = 0; e < nk && !dup; ++e) {
+      double s = 0.0;
+      for (int i = 0; i < N; ++i) s += raw[kept[e]].len[i] - r.len[i];
+      if (A.le(s, 0.01)) dup = true;  // an equal word exists
+    }
+    if (dup) continue;
+    double total = 0.0;
+    for (int i = 0; i < N; ++i) total += fabs(r.len[i]);
+    if (A.ge(total, 1000.0)) continue;  // MAX_LENGTH (:6)
+    if (!A.ge(total, 0.01)) {
+      degenerate = true;
+      continue;
+    }
+    kept[nk++] = gen;
+    acc |= 1ull << gen;
+    PpRsCand cnd;
+    for (int i = 0; i < 5; ++i) cnd.len[i] = r.len[i];
+    cnd.total = total;
+    cnd.word = r.word;
+    cnd.nseg = N;
+    slots[gen] = cnd;
+  }
+  *flags = (degenerate ? 4u : 0u) | (A.amb ? 2u : 0u);
+  return acc;
+}
+
 // generate_path, :707-725: the families in the reference's order.
 template <class Sink>
 __device__ __forceinline__ void pp_rs_generate(double sx, double sy, double syaw, double gx, double gy,

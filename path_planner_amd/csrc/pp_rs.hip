@@ -469,8 +469,8 @@ constexpr uint32_t kShotBulkMin = 16384;  // pairs; above this every CU holds ma
 // handles the pairs with np_above < n_paths <= kMaxPaths
 template <int kShotThreads, int kMaxPaths>
 __device__ __forceinline__ void
-pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, const double* __restrict__ sy,
-             const double* __restrict__ syaw, double maxc, double step_size, uint32_t check_step,
+pp_shot_pair(const uint32_t pair, int np_above, const double x0, const double y0, const double yaw0, double maxc,
+             double step_size, uint32_t check_step,
              const PpCostParams& cp, const PpRsCand* pc /* the pair's 46 candidate slots */, const PpRsPair pr,
              const PpFootprint& f, const PpLattice& lat, const PpBuckets& bk, int use_lattice,
              PpShotOut* __restrict__ out, pp_rs_word* __restrict__ word_out /* optional: the accepted path's word */) {
@@ -502,14 +502,22 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
     const PpRsCand c = pc[gen_of[lane]];
     plan_chain(c, step, plans[lane]);
     trim_path(plans[lane], maxc);
-    double len[5];
-    for (int i = 0; i < 5; ++i) len[i] = c.len[i] / maxc;
-    costs[lane] = rs_cost(len, c.word, c.nseg, cp);
+    if (kShotThreads < 128) {
+      double len[5];
+      for (int i = 0; i < 5; ++i) len[i] = c.len[i] / maxc;
+      costs[lane] = rs_cost(len, c.word, c.nseg, cp);
+    }
     hit[lane] = 0;
     my_tasks = (uint32_t)((plans[lane].npts + (int)check_step - 1) / (int)check_step);
   }
   // sampled poses per path (read by the task loop) and their maximum
   if (lane < np) n_samples[lane] = my_tasks;
+  if (kShotThreads >= 128 && lane >= 64 && lane < 64 + np) {  // the costs meanwhile, on the second wave
+    const PpRsCand c = pc[gen_of[lane - 64]];
+    double len[5];
+    for (int i = 0; i < 5; ++i) len[i] = c.len[i] / maxc;
+    costs[lane - 64] = rs_cost(len, c.word, c.nseg, cp);
+  }
   if (lane < 64) {
     uint32_t mx = my_tasks;
 #pragma unroll
@@ -527,7 +535,7 @@ pp_shot_pair(const uint32_t pair, int np_above, const double* __restrict__ sx, c
   // say; once every path is settled the remaining samples cannot change the outcome and the
   // workgroup stops testing.  (A stale count only means a few tests too many.)
   const uint32_t nslots = np ? n_samples[kMaxPaths] * (uint32_t)np : 0u;
-  const double x0 = sx[pair], y0 = sy[pair], yaw0 = syaw[pair], rmaxc = 1.0 / maxc;
+  const double rmaxc = 1.0 / maxc;
   double s0, c0;
   sincos(yaw0, &s0, &c0);
   for (uint32_t t = lane; t < nslots; t += kShotThreads) {
@@ -613,7 +621,8 @@ k_rs_shot(uint32_t n, int np_above, const double* __restrict__ sx, const double*
           PpFootprint f, PpLattice lat, PpBuckets bk, int use_lattice, PpShotOut* __restrict__ out,
           pp_rs_word* __restrict__ word_out) {
   if (blockIdx.x >= n) return;
-  pp_shot_pair<kShotThreads, kMaxPaths>(blockIdx.x, np_above, sx, sy, syaw, maxc, step_size, check_step, cp,
+  pp_shot_pair<kShotThreads, kMaxPaths>(blockIdx.x, np_above, sx[blockIdx.x], sy[blockIdx.x], syaw[blockIdx.x], maxc,
+                                        step_size, check_step, cp,
                                         cands + (size_t)blockIdx.x * PP_RS_MAX_PATHS, pairs[blockIdx.x], f, lat, bk,
                                         use_lattice, out, word_out);
 }
@@ -645,14 +654,22 @@ k_round(uint32_t n, const double* __restrict__ q6 /* sx sy syaw gx gy gyaw, n ea
     __shared__ unsigned long long s_acc;
     __shared__ uint32_t s_fl;
     __shared__ PpRsPair s_pair;
+    __shared__ double s_start[3];
     const uint32_t i = blockIdx.x, wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
     if (threadIdx.x == 0) {
       s_acc = 0ull;
       s_fl = 0u;
     }
     if (wave < 12u && wl < 4u) {
-      const PpRsInput in = pp_rs_input(q6[i], q6[n + i], q6[2 * (size_t)n + i], q6[3 * (size_t)n + i],
-                                       q6[4 * (size_t)n + i], q6[5 * (size_t)n + i], maxc);
+      // the start pose comes over PCIe when the round runs on the pinned area: read once, kept in LDS
+      const double qx = q6[i], qy = q6[n + i], qyaw = q6[2 * (size_t)n + i];
+      if (threadIdx.x == 0) {
+        s_start[0] = qx;
+        s_start[1] = qy;
+        s_start[2] = qyaw;
+      }
+      const PpRsInput in = pp_rs_input(qx, qy, qyaw, q6[3 * (size_t)n + i], q6[4 * (size_t)n + i],
+                                       q6[5 * (size_t)n + i], maxc);
       PpAmb A{false};
       pp_rs_eval_wave(in, (int)wave, (int)wl, A, s_raw);
       if (A.amb) atomicOr(&s_fl, 2u);
@@ -675,7 +692,7 @@ k_round(uint32_t n, const double* __restrict__ q6 /* sx sy syaw gx gy gyaw, n ea
     }
     __syncthreads();
     PP_STAMP(2);
-    pp_shot_pair<kRoundThreads, PP_RS_MAX_PATHS>(i, -1, q6, q6 + n, q6 + 2 * (size_t)n, maxc, step_size, check_step,
+    pp_shot_pair<kRoundThreads, PP_RS_MAX_PATHS>(i, -1, s_start[0], s_start[1], s_start[2], maxc, step_size, check_step,
                                                  cp, s_cands, s_pair, f, lat, bk, use_lattice, out, nullptr);
     return;
   }

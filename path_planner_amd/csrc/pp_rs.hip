@@ -542,7 +542,9 @@ pp_shot_pair(const uint32_t pair, int np_above, const double x0, const double y0
     if (*(volatile uint32_t*)&n_settled >= (uint32_t)np) break;
     const uint32_t k = t / (uint32_t)np;
     const int p = (int)(t - k * (uint32_t)np);
-    if (k >= n_samples[p]) continue;
+    // a settled path needs no more tests (a candidate can be thousands of metres long, and every
+    // lane of the workgroup would otherwise walk it to its end)
+    if (k >= n_samples[p] || (*(volatile uint32_t*)&hit[p] & kShotSettled)) continue;
     const int j = (int)k * (int)check_step;
     double X, Y, c, s;
     global_pose_for_test(plans[p], j, rmaxc, x0, y0, c0, s0, X, Y, c, s);

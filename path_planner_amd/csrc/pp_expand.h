@@ -36,6 +36,11 @@ struct PpExpandDev {
   // bit 4 of its valid byte: its f cost must not be used.
   const uint8_t* hobs = nullptr;
   double h_limit = 0.0;
+  // optional, instead of hmaps: the grids as the relaxation leaves them, in its blocked working
+  // layout (pp_blocked_value); grid p occupies stored columns p * hblk_plane_cols onwards
+  const double* hblk = nullptr;
+  uint32_t hblk_nty = 0;
+  uint64_t hblk_plane_cols = 0;
 };
 
 struct PpExpandPlan {

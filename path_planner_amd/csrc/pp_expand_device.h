@@ -13,6 +13,19 @@ __device__ __forceinline__ void pp_turn(double& c, double& s, double cd, double 
   s = ns;
 }
 
+// Cell (x, y) (stored column, row) of the heuristic relaxation's blocked array: 32x32-cell blocks
+// of 1024 doubles, block (x >> 5, y >> 5) at index (x >> 5) * nty + (y >> 5); inside a block the
+// 4x4 patch of cells (x & 3, y & 3) belongs to lane ((x & 31) >> 2) * 8 + ((y & 31) >> 2), cells
+// 2m, 2m+1 of a lane are adjacent and the 64 lanes of a pair consecutive (blk_off in
+// pp_heuristic.hip, which owns the layout).
+__device__ __forceinline__ double pp_blocked_value(const double* __restrict__ blk, uint32_t nty, uint64_t x,
+                                                   uint64_t y) {
+  const uint64_t t = (x >> 5) * nty + (y >> 5);
+  const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
+  const uint32_t k = (lx & 3u) * 4u + (ly & 3u), lane = (lx >> 2) * 8u + (ly >> 2);
+  return blk[t * 1024u + ((k >> 1) * 64u + lane) * 2u + (k & 1u)];
+}
+
 // Item t = parent t / n_prim, primitive t % n_prim.  pflag, when given, holds the result of the
 // parent's own pose (the first pose of every primitive).
 __device__ __forceinline__ void pp_expand_item(uint64_t t, uint32_t n_prim, const double* __restrict__ px,
@@ -89,9 +102,10 @@ __device__ __forceinline__ void pp_expand_item(uint64_t t, uint32_t n_prim, cons
     if (valid) {
       // is_index_ok guarantees minx < xind < maxx, so the lookup is inside the grid
       uint64_t hx = xind - prm.minx, hy = yind - prm.miny;
-      const double* hm = out.hmaps[out.hmap_id[p]];
       if (hx < out.hxw && hy < out.hyw) {
-        const double h = hm[hx * out.hyw + hy];
+        const double h = out.hblk ? pp_blocked_value(out.hblk, out.hblk_nty,
+                                                     (uint64_t)out.hmap_id[p] * out.hblk_plane_cols + hx, hy)
+                                  : out.hmaps[out.hmap_id[p]][hx * out.hyw + hy];
         fc = cost + out.h_cost * h;
         if (out.hobs && h > out.h_limit && !out.hobs[hx * out.hyw + hy]) v |= 16u;
       } else {

@@ -639,6 +639,7 @@ struct WaveResume {
   TileRun run;
   DenseView d;
   unsigned sg;
+  bool unpack;  // the caller reads the dense arrays (false: it reads the blocked array itself)
 };
 void wave_resume_drop(pp_ctx* ctx) {
   delete (WaveResume*)ctx->wave_resume;
@@ -775,6 +776,12 @@ extern "C" int32_t pp_wavefront_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const
 // every cell whose final value is at most the limit has it, the others hold an upper bound or
 // +inf.  The working state stays in the context and pp_wavefront_multi_finish completes the grids;
 // *bounded tells the caller whether that is the case.
+static uint32_t multi_per_pass(uint64_t xw, uint64_t yw, uint32_t n) {
+  const uint64_t plane_tiles = ((xw + 1 + kTile - 1) / kTile + 1) * ((yw + kTile - 1) / kTile);
+  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, ((uint64_t)1 << 20) / plane_tiles));
+}
+bool pp_wavefront_multi_single_pass(uint64_t xw, uint64_t yw, uint32_t n) { return multi_per_pass(xw, yw, n) >= n; }
+
 int32_t pp_wavefront_multi_finish(pp_ctx* ctx) {
   if (!ctx) return PP_ERR_INVALID;
   WaveResume* r = (WaveResume*)ctx->wave_resume;
@@ -784,7 +791,8 @@ int32_t pp_wavefront_multi_finish(pp_ctx* ctx) {
   uint32_t status[4];
   int32_t st = tile_run(ctx, r->run, nullptr, status);
   if (st == PP_OK) {
-    hipLaunchKernelGGL(k_tile_unpack, dim3(r->sg), dim3(256), 0, ctx->stream, r->d, r->run.g, r->run.nblocks);
+    if (r->unpack)
+      hipLaunchKernelGGL(k_tile_unpack, dim3(r->sg), dim3(256), 0, ctx->stream, r->d, r->run.g, r->run.nblocks);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) st = PP_ERR_HIP;
@@ -795,15 +803,15 @@ int32_t pp_wavefront_multi_finish(pp_ctx* ctx) {
 
 int32_t pp_wavefront_multi_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint8_t* d_obs, uint32_t n,
                                const uint64_t* goal_x, const uint64_t* goal_y, double* d_cost,
-                               uint64_t cost_stride, double limit, bool* bounded) {
+                               uint64_t cost_stride, double limit, bool* bounded, PpBlockedGrids* keep_blocked) {
   if (bounded) *bounded = false;
-  if (!ctx || !d_obs || !d_cost || !goal_x || !goal_y) return PP_ERR_INVALID;
+  if (keep_blocked && !pp_wavefront_multi_single_pass(xw, yw, n)) return PP_ERR_INVALID;
+  if (!ctx || !d_obs || (!d_cost && !keep_blocked) || !goal_x || !goal_y) return PP_ERR_INVALID;
   if (n == 0) return PP_OK;
   if (xw == 0 || yw == 0 || xw >= ((uint64_t)1 << 31) || yw >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
   PP_HIP(ctx, hipSetDevice(ctx->device));
   // planes per pass: keep the blocked working copy under ~8 GiB
-  const uint64_t plane_tiles = ((xw + 1 + kTile - 1) / kTile + 1) * ((yw + kTile - 1) / kTile);
-  const uint32_t per_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, ((uint64_t)1 << 20) / plane_tiles));
+  const uint32_t per_pass = multi_per_pass(xw, yw, n);
   std::vector<int64_t> hg(2 * (size_t)per_pass);
   for (uint32_t p0 = 0; p0 < n; p0 += per_pass) {
     const uint32_t np = std::min(per_pass, n - p0);
@@ -831,11 +839,14 @@ int32_t pp_wavefront_multi_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint
     uint32_t status[4];
     st = tile_run(ctx, run, nullptr, status);
     if (st != PP_OK) return st;
-    hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks);
+    if (!keep_blocked)
+      hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks);
+    else
+      *keep_blocked = PpBlockedGrids{run.g.blk, run.g.nty, xw + 1};
     PP_HIP(ctx, hipGetLastError());
     PP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // d_goals is reused by the next pass
     if (bound) {
-      ctx->wave_resume = new WaveResume{run, d, sg};
+      ctx->wave_resume = new WaveResume{run, d, sg, keep_blocked == nullptr};
       ctx->wave_resume_free = [](void* p) { delete (WaveResume*)p; };
       if (bounded) *bounded = true;
     }

@@ -120,8 +120,18 @@ struct pp_map {
 int32_t pp_scratch_reserve(pp_ctx* ctx, size_t bytes);
 int32_t pp_wavefront_multi_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint8_t* d_obs, uint32_t n,
                                const uint64_t* goal_x, const uint64_t* goal_y, double* d_cost,
-                               uint64_t cost_stride, double limit = __builtin_inf(), bool* bounded = nullptr);
+                               uint64_t cost_stride, double limit = __builtin_inf(), bool* bounded = nullptr,
+                               struct PpBlockedGrids* keep_blocked = nullptr);
 int32_t pp_wavefront_multi_finish(pp_ctx* ctx);
+// Where pp_wavefront_multi_dev left the grids when asked to keep them in the relaxation's blocked
+// layout instead of writing the dense arrays (valid until the context's next relaxation).
+struct PpBlockedGrids {
+  const double* blk = nullptr;
+  uint32_t nty = 0;
+  uint64_t plane_cols = 0;
+};
+// True when n grids of that size are relaxed in one pass (a precondition of keeping them blocked).
+bool pp_wavefront_multi_single_pass(uint64_t xw, uint64_t yw, uint32_t n);
 int32_t pp_pinned_reserve(pp_ctx* ctx, size_t bytes);
 PpFootprint pp_make_footprint(const pp_config* conf);
 int32_t pp_check_config(const pp_config* conf);

@@ -21,7 +21,7 @@
 #include <thread>
 #include <unordered_map>
 
-#include "pp_expand.h"
+#include "pp_expand_device.h"
 #include "pp_internal.h"
 #include "pp_rs.h"
 
@@ -296,6 +296,15 @@ __global__ void k_gather_hmap(uint32_t n, const double* const* __restrict__ tab,
   if (i < n) out[i] = tab[slot[i]][off[i]];
 }
 
+__global__ void k_gather_blocked(uint32_t n, PpBlockedGrids g, uint64_t hyw, const int32_t* __restrict__ slot,
+                                 const uint64_t* __restrict__ off, double* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint64_t hx = off[i] / hyw, hy = off[i] - hx * hyw;
+    out[i] = pp_blocked_value(g.blk, g.nty, (uint64_t)slot[i] * g.plane_cols + hx, hy);
+  }
+}
+
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -367,14 +376,19 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   }
   const size_t ngoals = goal_cells.size();
   double h_limit = __builtin_inf();
-  bool h_bounded = false;
+  bool h_bounded = false, keep_blocked = false;
+  PpBlockedGrids blocked;
   // heuristic grids, raster and pointer table share one buffer kept in the context
   struct {
     void* p = nullptr;
   } hm_buf, obs_buf, tab_buf;
   std::vector<double*> hm_ptr(ngoals);
   if (ngoals) {
-    const size_t b_hm = ngoals * al256(hcells * 8), b_obs = al256(hcells), b_tab = al256(ngoals * sizeof(double*));
+    // Relaxed in one pass (the usual case), the grids stay in the relaxation's blocked working array
+    // and the searches read them there; otherwise they are written out as dense arrays.
+    keep_blocked = pp_wavefront_multi_single_pass(hxw, hyw, (uint32_t)ngoals);
+    const size_t b_hm = keep_blocked ? 0 : ngoals * al256(hcells * 8), b_obs = al256(hcells),
+                 b_tab = al256(ngoals * sizeof(double*));
     if (b_hm + b_obs + b_tab > ctx->hmap_bytes) {
       if (ctx->hmap_buf) PP_HIP(ctx, hipFree(ctx->hmap_buf));
       ctx->hmap_buf = nullptr;
@@ -403,10 +417,13 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     if (const char* e = getenv("PP_HEURISTIC_LIMIT")) h_limit = atof(e);  // testing: any value is safe
     if (!(h_limit >= 0.0)) h_limit = __builtin_inf();
     st = pp_wavefront_multi_dev(ctx, hxw, hyw, (const uint8_t*)obs_buf.p, (uint32_t)ngoals, ggx.data(),
-                                ggy.data(), (double*)hm_buf.p, al256(hcells * 8) / 8, h_limit, &h_bounded);
+                                ggy.data(), keep_blocked ? nullptr : (double*)hm_buf.p, al256(hcells * 8) / 8,
+                                h_limit, &h_bounded, keep_blocked ? &blocked : nullptr);
     if (st != PP_OK) return st;
-    PP_HIP(ctx, hipMemcpyAsync(tab_buf.p, hm_ptr.data(), ngoals * sizeof(double*), hipMemcpyHostToDevice, s));
-    PP_HIP(ctx, hipStreamSynchronize(s));
+    if (!keep_blocked) {
+      PP_HIP(ctx, hipMemcpyAsync(tab_buf.p, hm_ptr.data(), ngoals * sizeof(double*), hipMemcpyHostToDevice, s));
+      PP_HIP(ctx, hipStreamSynchronize(s));
+    }
   }
   const double t_heur = now_ms();
 
@@ -453,9 +470,17 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       char* b = (char*)ctx->scratch;
       PP_HIP(ctx, hipMemcpyAsync(b, g_slot.data(), ng * 4, hipMemcpyHostToDevice, s));
       PP_HIP(ctx, hipMemcpyAsync(b + b4, g_off.data(), ng * 8, hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(k_gather_hmap, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
-                         (const double* const*)tab_buf.p, (const int32_t*)b, (const uint64_t*)(b + b4),
-                         (double*)(b + b4 + b8));
+      if (keep_blocked)
+        hipLaunchKernelGGL(k_gather_blocked, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
+                           blocked, hyw, (const int32_t*)b, (const uint64_t*)(b + b4), (double*)(b + b4 + b8));
+      else
+        if (keep_blocked)
+          hipLaunchKernelGGL(k_gather_blocked, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
+                             blocked, hyw, (const int32_t*)b, (const uint64_t*)(b + b4), (double*)(b + b4 + b8));
+        else
+          hipLaunchKernelGGL(k_gather_hmap, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
+                             (const double* const*)tab_buf.p, (const int32_t*)b, (const uint64_t*)(b + b4),
+                             (double*)(b + b4 + b8));
       PP_HIP(ctx, hipGetLastError());
       PP_HIP(ctx, hipMemcpyAsync(hval.data(), b + b4 + b8, ng * 8, hipMemcpyDeviceToHost, s));
       PP_HIP(ctx, hipStreamSynchronize(s));
@@ -470,9 +495,13 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         h_bounded = false;
         const size_t b4 = al256(ng * 4), b8 = al256(ng * 8);
         char* b = (char*)ctx->scratch;
-        hipLaunchKernelGGL(k_gather_hmap, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
-                           (const double* const*)tab_buf.p, (const int32_t*)b, (const uint64_t*)(b + b4),
-                           (double*)(b + b4 + b8));
+        if (keep_blocked)
+          hipLaunchKernelGGL(k_gather_blocked, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
+                             blocked, hyw, (const int32_t*)b, (const uint64_t*)(b + b4), (double*)(b + b4 + b8));
+        else
+          hipLaunchKernelGGL(k_gather_hmap, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
+                             (const double* const*)tab_buf.p, (const int32_t*)b, (const uint64_t*)(b + b4),
+                             (double*)(b + b4 + b8));
         PP_HIP(ctx, hipGetLastError());
         PP_HIP(ctx, hipMemcpyAsync(hval.data(), b + b4 + b8, ng * 8, hipMemcpyDeviceToHost, s));
         PP_HIP(ctx, hipStreamSynchronize(s));
@@ -533,6 +562,11 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
 
   PpExpandDev eo{};
   eo.hmaps = (const double* const*)tab_buf.p;
+  if (keep_blocked) {
+    eo.hblk = blocked.blk;
+    eo.hblk_nty = blocked.nty;
+    eo.hblk_plane_cols = blocked.plane_cols;
+  }
   eo.hxw = hxw;
   eo.hyw = hyw;
   eo.h_cost = conf->h_cost;

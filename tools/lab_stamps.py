@@ -1,3 +1,8 @@
+"""Phase times of the planner's round kernel for the demo query (experiments only).
+
+Needs a library built with -DPP_LAB_STAMPS=1 on pp_rs.hip (SRC=pp_rs tools/variant.sh stamps
+-DPP_LAB_STAMPS=1) and PP_HIP_LIB pointing at it: workgroup 0 of k_round records the 100 MHz wall
+clock at its phase boundaries and pp_lab_stamps() copies the stamps out."""
 import ctypes as C, os, sys, numpy as np
 sys.path.insert(0, os.getcwd())
 from path_planner_amd import _abi as A, api, workloads as W

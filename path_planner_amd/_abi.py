@@ -166,6 +166,8 @@ def load_library(path=None):
         "pp_analytic_batch": (C.c_int32, [vp, vp, cfg, C.c_uint64, d, d, d, d, d, d, u8, i32, i32,
                                           C.POINTER(RsWord), d]),
         "pp_analytic_batch_dev": (C.c_int32, [vp, vp, cfg, C.c_uint64, vp, vp, vp, vp, vp, vp]),
+        "pp_analytic_batch_dev_static": (C.c_int32, [vp, vp, cfg, C.c_uint64, vp, vp, vp, vp, vp, vp]),
+        "pp_analytic_static_max": (C.c_uint64, []),
         "pp_plan": (C.c_int32, [vp, vp, cfg, d, d, C.POINTER(Path), C.POINTER(PlanStats)]),
         "pp_plan_batch": (C.c_int32, [vp, vp, cfg, C.c_uint64, d, d, C.POINTER(Path),
                                       C.POINTER(PlanStats), i32]),

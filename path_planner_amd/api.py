@@ -295,6 +295,16 @@ def analytic_expansion_dev(ctx, omap, conf, q6, found, idx, npaths, words, cost)
                                        cost.data_ptr()), "pp_analytic_batch_dev")
 
 
+def analytic_expansion_dev_static(ctx, omap, conf, q6, found, idx, npaths, words, cost):
+    """analytic_expansion_dev through the entry point that allocates nothing (at most
+    pp_analytic_static_max() pairs; PP_ERR_CAPACITY above)."""
+    n = q6.shape[1]
+    _chk(ctx.lib.pp_analytic_batch_dev_static(ctx.h, omap.h, C.byref(conf), n, q6.data_ptr(),
+                                              found.data_ptr(), idx.data_ptr(), npaths.data_ptr(),
+                                              words.data_ptr(), cost.data_ptr()),
+         "pp_analytic_batch_dev_static")
+
+
 # ------------------------------------------------------------------ the planner
 def hybrid_astar_planning(ctx, omap, conf, sx, sy, syaw, gx, gy, gyaw, cap=200000,
                           closed_cap=1 << 20):

@@ -3,6 +3,7 @@
 // (generate_local_course / interpolate / global transform, :87-128, :581-705) and the
 // analytic-expansion shot of the planner (hybrid_astar.rs:380-415, :450-489).
 #include <algorithm>
+#include <mutex>
 
 #include "pp_device.h"
 #include <vector>
@@ -1254,4 +1255,75 @@ extern "C" int32_t pp_analytic_batch(pp_ctx* ctx, const pp_map* map, const pp_co
     if (o.flags & 16u) ret = PP_ERR_NONFINITE;
   }
   return ret;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pp_analytic_batch_dev for callers that must not allocate (under stream capture, in a serving
+// loop, in a harness that forbids hipMalloc).  Its intermediate records -- the candidate words of
+// every pair, the per-pair summaries and the shot results the unpack kernel reads -- live in one
+// array of device memory that comes with the library instead of in the context's grown-on-demand
+// buffer.  Every GPU the library runs on holds its own copy of the array for the life of the
+// process; the host finds a device's copy once, by symbol, and hands that address to the kernels.
+
+namespace {
+
+constexpr uint64_t kStaticMaxPairs = 4096;
+constexpr size_t kStaticCandBytes = (kStaticMaxPairs * PP_RS_MAX_PATHS * sizeof(PpRsCand) + 255) & ~(size_t)255;
+constexpr size_t kStaticPairBytes = (kStaticMaxPairs * sizeof(PpRsPair) + 255) & ~(size_t)255;
+constexpr size_t kStaticOutBytes = (kStaticMaxPairs * sizeof(PpShotOut) + 255) & ~(size_t)255;
+constexpr size_t kStaticBytes = kStaticCandBytes + kStaticPairBytes + kStaticOutBytes;  // 10.3 MiB
+
+constexpr int kStaticMaxDevices = 64;
+void* g_static_ptr[kStaticMaxDevices];  // device address of `scratch` per HIP ordinal, 0 = not looked up
+std::mutex g_static_mu;
+
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+// Device address of this device's copy of `scratch` (the device must be current).
+static int32_t static_scratch(pp_ctx* ctx, unsigned char** out) {
+  if (ctx->device < 0 || ctx->device >= kStaticMaxDevices) return PP_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lk(g_static_mu);
+  if (!g_static_ptr[ctx->device]) {
+    void* p = nullptr;
+    PP_HIP(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return PP_ERR_HIP;
+    g_static_ptr[ctx->device] = p;
+  }
+  *out = (unsigned char*)g_static_ptr[ctx->device];
+  return PP_OK;
+}
+
+extern "C" uint64_t pp_analytic_static_max(void) { return kStaticMaxPairs; }
+
+extern "C" int32_t pp_analytic_batch_dev_static(pp_ctx* ctx, const pp_map* map, const pp_config* conf,
+                                                uint64_t n, const double* d_q6, uint8_t* d_found,
+                                                int32_t* d_path_idx, int32_t* d_n_paths,
+                                                pp_rs_word* d_word, double* d_rs_cost) {
+  if (!ctx || !map || !conf) return PP_ERR_INVALID;
+  if (map->ox.empty()) return PP_ERR_EMPTY_MAP;
+  if (!map->finite) return PP_ERR_NONFINITE;
+  if (n == 0) return PP_OK;
+  if (n > kStaticMaxPairs) return PP_ERR_CAPACITY;  // the array holds the records of 4096 pairs
+  if (!d_q6 || !d_found || !d_path_idx || !d_n_paths || !d_word || !d_rs_cost) return PP_ERR_INVALID;
+  int32_t st = pp_check_config(conf);
+  if (st != PP_OK) return st;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned char* base = nullptr;
+  st = static_scratch(ctx, &base);
+  if (st != PP_OK) return st;
+  // Nothing in the array has to start at zero: the word kernel writes a pair's summary and the
+  // candidates its `accepted` bits name before the shot kernel reads them, and the shot kernel
+  // writes every result record the unpack kernel reads, all in stream order.
+  PpRsCand* d_c = (PpRsCand*)base;
+  PpRsPair* d_p = (PpRsPair*)(base + kStaticCandBytes);
+  PpShotOut* d_o = (PpShotOut*)(base + kStaticCandBytes + kStaticPairBytes);
+  const double maxc = std::tan(conf->max_steer) / conf->car.wheel_base;  // hybrid_astar.rs:388
+  pp_rs_words_launch(ctx, n, d_q6, maxc, d_c, d_p);
+  pp_rs_shot_launch(ctx, map, conf, (uint32_t)n, d_q6, maxc, d_c, d_p, d_o, d_word);
+  hipLaunchKernelGGL(k_shot_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (uint32_t)n, d_o, d_found, d_path_idx, d_n_paths, d_rs_cost);
+  PP_HIP(ctx, hipGetLastError());
+  return PP_OK;
 }

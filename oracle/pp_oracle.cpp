@@ -1271,6 +1271,7 @@ int32_t orc_plan(const orc_map* m, const pp_config* conf_, const double start[3]
   uint64_t* closed_order = S->closed_order;
   S->expansions = S->stale_pops = S->rollouts = S->poses_checked = S->rs_paths = S->ambiguous = 0;
   S->rs_final_length = 0.0;
+  S->first_ambiguous = UINT64_MAX;  // the oracle takes no guard-band decisions
 
   while (!open_set.empty()) {
     if (g_max_expansions && S->expansions >= g_max_expansions) return PP_ERR_LIMIT;

@@ -81,7 +81,7 @@ class PlanStats(C.Structure):
                 ("poses_checked", C.c_uint64), ("rs_paths", C.c_uint64), ("ambiguous", C.c_uint64),
                 ("closed_cap", C.c_uint64), ("closed_order", c_u64_p),
                 ("rs_final_length", C.c_double), ("t_heuristic_ms", C.c_double),
-                ("t_search_ms", C.c_double)]
+                ("t_search_ms", C.c_double), ("first_ambiguous", C.c_uint64)]
 
 
 class ExpandOut(C.Structure):

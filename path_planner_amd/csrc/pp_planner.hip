@@ -355,6 +355,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     std::memcpy(q.start, starts + 3 * i, 24);
     std::memcpy(q.goal, goals + 3 * i, 24);
     q.st = pp_plan_stats{};
+    q.st.first_ambiguous = UINT64_MAX;
     if (stats) {
       q.st.closed_cap = stats[i].closed_cap;
       q.st.closed_order = stats[i].closed_order;
@@ -598,7 +599,11 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     const PpShotOut& so = *v.shot;
     q.st.rs_paths += (uint64_t)so.n_paths;
     q.st.poses_checked += so.poses_handed;
-    if (so.flags & 2u) ++q.st.ambiguous;
+    // the node being expanded is the last one closed: position expansions - 1 of the closing order
+    auto guard_band = [&q] {
+      if (q.st.ambiguous++ == 0) q.st.first_ambiguous = q.st.expansions - 1;
+    };
+    if (so.flags & 2u) guard_band();
     if (so.flags & (4u | 8u | 16u)) {
       q.status = (so.flags & 4u) ? PP_ERR_DEGENERATE_RS : (so.flags & 8u) ? PP_ERR_NAN_COST : PP_ERR_NONFINITE;
       q.live = false;
@@ -616,7 +621,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       ++q.st.rollouts;
       const uint8_t vf = v.valid[i];
       if (vf & 8u) q.st.poses_checked += checks;
-      if (vf & 2u) ++q.st.ambiguous;
+      if (vf & 2u) guard_band();
       if (vf & 4u) {
         q.status = PP_ERR_NONFINITE;
         q.live = false;

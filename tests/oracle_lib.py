@@ -243,6 +243,16 @@ def unpack_paths(st, n, words, off, tx, ty, tyaw, td):
     return st, paths
 
 
+def rs_words(q0, q1, maxc):
+    """generate_path's words for one pair, in generation order: [(ctypes, lengths, total)] with
+    lengths in metres."""
+    n = C.c_int32(0)
+    words = (A.RsWord * A.PP_RS_MAX_PATHS)()
+    st = lib().orc_rs_words(*map(float, q0), *map(float, q1), maxc, C.byref(n), words)
+    assert st == 0, st
+    return [(words[k].word(), words[k].lens(), words[k].total_length) for k in range(n.value)]
+
+
 def rs_batch(s, g, maxc, threads=1):
     s, g = _f64(s).reshape(-1, 3), _f64(g).reshape(-1, 3)
     n = len(s)

@@ -7,7 +7,7 @@ import oracle_lib as O
 from path_planner_amd import _abi as A
 from path_planner_amd import api
 from path_planner_amd import workloads as W
-from test_oracle_astar import astar_env
+from test_oracle_astar import astar_env, check_astar_fixture
 
 pytestmark = pytest.mark.gpu
 
@@ -28,6 +28,16 @@ def same(ctx, m, ox, oy, s, g, reso, rr):
     else:
         assert (got[0] == exp[0]).all() and (got[1] == exp[1]).all()
     return exp
+
+
+def test_against_the_patched_twin_fixture(ctx):
+    """tests/golden/astar_rust.json (the reference's Python twin with the crate's rounding and
+    heap tie rule)."""
+    def plan(ox, oy, sx, sy, gx, gy, reso, rr):
+        m = api.ObstacleMap(ctx, ox, oy)
+        got, order = api.astar_planning(ctx, m, sx, sy, gx, gy, reso, rr, closed_cap=1000000)
+        return (A.PP_NO_PATH if got is None else 0), got, order
+    check_astar_fixture(plan)
 
 
 def test_demo_environment(ctx):

@@ -165,6 +165,16 @@ def test_expand_vs_oracle(ctx):
     assert np.allclose(got["end_y"][v], exp["end_y"][v], rtol=1e-12, atol=1e-12)
 
 
+def test_expand_vs_unpatched_twin_fixture(ctx):
+    """tests/golden/twin_next_node.json: calc_next_node of the reference's Python twin on inputs
+    where it equals the crate (no yaw wrap, no rounding tie)."""
+    from test_oracle_golden import check_next_node_fixture
+    ox, oy = W.demo_obstacles()
+    m = api.ObstacleMap(ctx, ox, oy)
+    out = check_next_node_fixture(lambda *a: api.expand(ctx, m, CONF, *a))
+    assert ((out["valid"] & 2) != 0).sum() <= 2
+
+
 def test_rollout_points_vs_oracle(ctx):
     steer, direc = api.calc_motion_set(CONF)
     for i in (0, 19, 25, 50, 77):

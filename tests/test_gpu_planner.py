@@ -23,18 +23,6 @@ def ctx():
     c.close()
 
 
-def same_plan(r, e):
-    """True if the two runs agree; a disagreement is tolerated (False) only when the device
-    run reported a decision inside its guard band."""
-    try:
-        _same_plan(r, e)
-        return True
-    except AssertionError:
-        if r["stats"].ambiguous:
-            return False
-        raise
-
-
 def _same_plan(r, e):
     assert r["status"] == e["status"]
     S, E = r["stats"], e["stats"]
@@ -52,18 +40,60 @@ def _same_plan(r, e):
         assert abs(S.rs_final_length - E.rs_final_length) <= 1e-9 * E.rs_final_length
 
 
-def test_demo_query(ctx):
-    """src/main.rs:215-269."""
+def explained_by_guard_band(stats, closed, exp_closed):
+    """The bound a differing query is held to: the device reported a guard-band decision, and
+    everything it closed up to and including the node whose expansion took the first such decision
+    is the oracle's closing order (a different last bit in a libm can only act from there on)."""
+    assert stats.ambiguous > 0, "differs from the oracle without any guard-band decision"
+    k = int(stats.first_ambiguous) + 1
+    assert 1 <= k <= int(stats.expansions)
+    k = min(k, len(closed), len(exp_closed))
+    assert (np.asarray(closed[:k]) == np.asarray(exp_closed[:k])).all(), "differs before the first guard-band decision"
+
+
+def same_plan(r, e):
+    """True if the two runs agree in everything; False if they differ in a way the device's first
+    guard-band decision accounts for; raises otherwise."""
+    try:
+        _same_plan(r, e)
+        return True
+    except AssertionError:
+        explained_by_guard_band(r["stats"], r["closed"], e["closed"])
+        return False
+
+
+def test_no_guard_band_means_unset_position(ctx):
     ox, oy = W.demo_obstacles()
     m = api.ObstacleMap(ctx, ox, oy)
-    (sx, sy, syaw), (gx, gy, gyaw) = W.demo_query()
-    r = api.hybrid_astar_planning(ctx, m, CONF, sx, sy, syaw, gx, gy, gyaw)
-    e = O.OracleMap(ox, oy).plan(CONF, [sx, sy, syaw], [gx, gy, gyaw])
-    assert same_plan(r, e)
-    assert r["stats"].expansions == 24 and r["stats"].stale_pops == 11
-    assert r["closed"][:12].tolist() == [7980, 8004, 7304, 6604, 5881, 4758, 4760, 4361, 4736, 3986, 3563, 3539]
-    assert abs(r["cost"] - 561.4479147109321) < 1e-9 * 561.45
-    assert len(r["x"]) == 184 and r["stats"].poses_checked == 8951
+    r = api.hybrid_astar_planning(ctx, m, CONF, 30.0, 6.5, 0.3, 35.0, 7.0, 0.2)
+    if r["stats"].ambiguous == 0:
+        assert r["stats"].first_ambiguous == 2**64 - 1
+    else:
+        assert r["stats"].first_ambiguous < r["stats"].expansions
+
+
+def test_demo_and_random_queries_against_the_patched_twin(ctx):
+    """tests/golden/rust_semantics.json: the demo query of src/main.rs:215-269 and 24 random
+    demo-map queries from the reference's Python twin patched to the crate's semantics."""
+    from test_oracle_golden import check_rust_semantics_fixture
+    ox, oy = W.demo_obstacles()
+    m = api.ObstacleMap(ctx, ox, oy)
+    data, flagged = check_rust_semantics_fixture(
+        lambda s, g: api.hybrid_astar_planning(ctx, m, CONF, *s, *g), strict=False)
+    for qi, q, r in flagged:
+        explained_by_guard_band(r["stats"], r["closed"], q["closed"])
+    # the demo query itself takes no decision that a libm's last bit could turn
+    assert 0 not in [qi for qi, _, _ in flagged]
+    assert len(flagged) <= FLAGGED_FIXTURE, [qi for qi, _, _ in flagged]
+
+
+# Queries (fixed seeds) whose device run differs from the oracle's after a guard-band decision;
+# each of them passed explained_by_guard_band.  The numbers are what this build measures on an
+# MI355X; a change in them means a kernel's arithmetic changed and wants a look.
+FLAGGED_FIXTURE = 0
+FLAGGED_DEMO_RANDOM = 0
+FLAGGED_BATCH40 = 0
+FLAGGED_BATCH96 = 0
 
 
 def test_random_queries_on_demo_map(ctx):
@@ -71,20 +101,24 @@ def test_random_queries_on_demo_map(ctx):
     m = api.ObstacleMap(ctx, ox, oy)
     om = O.OracleMap(ox, oy)
     rng = np.random.default_rng(12)
-    checked = nopath = 0
+    differ = nopath = 0
     # unreachable goals never terminate in the reference (unwrapped yaw): cap both sides
     ctx.set_max_expansions(1500)
     O.set_max_expansions(1500)
-    for _ in range(25):
-        s = [rng.uniform(5, 45), rng.uniform(5, 25), rng.uniform(-math.pi, math.pi)]
-        g = [rng.uniform(5, 45), rng.uniform(5, 25), rng.uniform(-math.pi, math.pi)]
-        r = api.hybrid_astar_planning(ctx, m, CONF, *s, *g)
-        e = om.plan(CONF, s, g)
-        checked += bool(same_plan(r, e))
-        nopath += r["status"] != 0
-    ctx.set_max_expansions(100000)
-    O.set_max_expansions(0)
-    assert checked >= 22 and nopath < 20
+    try:
+        for _ in range(25):
+            s = [rng.uniform(5, 45), rng.uniform(5, 25), rng.uniform(-math.pi, math.pi)]
+            g = [rng.uniform(5, 45), rng.uniform(5, 25), rng.uniform(-math.pi, math.pi)]
+            r = api.hybrid_astar_planning(ctx, m, CONF, *s, *g)
+            e = om.plan(CONF, s, g)
+            differ += not same_plan(r, e)
+            nopath += r["status"] != 0
+    finally:
+        ctx.set_max_expansions(100000)
+        O.set_max_expansions(0)
+    print("differing after a guard-band decision:", differ)
+    assert differ <= FLAGGED_DEMO_RANDOM, differ
+    assert nopath < 20
 
 
 def test_plan_batch_matches_single_and_oracle(ctx):
@@ -97,42 +131,42 @@ def test_plan_batch_matches_single_and_oracle(ctx):
     goals_pool = np.c_[rng.uniform(15, 80, 4), rng.uniform(15, 80, 4), rng.uniform(-3, 3, 4)]
     starts = np.c_[rng.uniform(12, 84, n), rng.uniform(12, 84, n), rng.uniform(-3, 3, n)]
     goals = goals_pool[rng.integers(0, 4, n)]
-    lib = ctx.lib
     ctx.set_max_expansions(1500)
     O.set_max_expansions(1500)
-    cap, ccap = 20000, 1 << 16
-    X = np.zeros((n, cap)); Y = np.zeros((n, cap)); YAW = np.zeros((n, cap))
-    D = np.zeros((n, cap), np.int64)
-    closed = np.zeros((n, ccap), np.uint64)
-    paths = (A.Path * n)()
-    stats = (A.PlanStats * n)()
-    for i in range(n):
-        paths[i] = A.Path(X[i].ctypes.data_as(A.c_double_p), Y[i].ctypes.data_as(A.c_double_p),
-                          YAW[i].ctypes.data_as(A.c_double_p), D[i].ctypes.data_as(A.c_i64_p), cap, 0, 0.0)
-        stats[i].closed_cap = ccap
-        stats[i].closed_order = closed[i].ctypes.data_as(A.c_u64_p)
-    status = np.zeros(n, np.int32)
-    st = lib.pp_plan_batch(ctx.h, m.h, C.byref(CONF), n, np.ascontiguousarray(starts).ctypes.data_as(A.c_double_p),
-                           np.ascontiguousarray(goals).ctypes.data_as(A.c_double_p), paths, stats,
-                           status.ctypes.data_as(A.c_i32_p))
-    assert st == 0
-    ok = 0
-    for i in range(n):
-        e = om.plan(CONF, starts[i], goals[i])
-        assert status[i] == e["status"]
-        ne = int(stats[i].expansions)
-        if stats[i].ambiguous and (ne != e["stats"].expansions or (closed[i, :ne] != e["closed"]).any()):
-            continue
-        assert ne == e["stats"].expansions
-        assert (closed[i, :ne] == e["closed"]).all()
-        if status[i] == 0:
-            L = int(paths[i].len)
-            assert L == len(e["x"]) and abs(paths[i].cost - e["cost"]) <= 1e-9 * e["cost"]
-            assert np.allclose(X[i, :L], e["x"], rtol=1e-9, atol=1e-9)
-            ok += 1
-    ctx.set_max_expansions(100000)
-    O.set_max_expansions(0)
-    assert ok >= n // 2
+    try:
+        r = api.plan_batch(ctx, m, CONF, starts, goals, cap=20000, closed_cap=1 << 12)
+        differ = found = 0
+        for i in range(n):
+            e = om.plan(CONF, starts[i], goals[i])
+            differ += not same_batch_query(r, i, e, 1 << 12)
+            found += r["status"][i] == 0
+    finally:
+        ctx.set_max_expansions(100000)
+        O.set_max_expansions(0)
+    print("differing after a guard-band decision:", differ)
+    assert differ <= FLAGGED_BATCH40, differ
+    assert found >= n // 2
+
+
+def same_batch_query(r, i, e, closed_cap):
+    """Query i of a plan_batch result against the oracle's run: same_plan's three outcomes."""
+    S = r["stats"][i]
+    ne = int(S.expansions)
+    closed = r["closed"][i, :min(ne, closed_cap)]
+    E = e["stats"]
+    same = (r["status"][i] == e["status"] and ne == E.expansions and
+            (closed == e["closed"][:closed_cap]).all() and S.stale_pops == E.stale_pops and
+            S.rollouts == E.rollouts and S.rs_paths == E.rs_paths and S.poses_checked == E.poses_checked)
+    if same and e["status"] == 0:
+        L = int(r["len"][i])
+        same = (L == len(e["x"]) and abs(r["cost"][i] - e["cost"]) <= 1e-9 * abs(e["cost"]) and
+                np.allclose(r["x"][i, :L], e["x"], rtol=1e-9, atol=1e-9) and
+                np.allclose(r["y"][i, :L], e["y"], rtol=1e-9, atol=1e-9) and
+                np.allclose(r["yaw"][i, :L], e["yaw"], rtol=1e-9, atol=1e-9) and
+                (r["dir"][i, :L] == e["dir"]).all())
+    if not same:
+        explained_by_guard_band(S, closed, e["closed"])
+    return same
 
 
 def test_plan_error_paths(ctx):
@@ -154,7 +188,8 @@ def test_plan_error_paths(ctx):
     ctx.set_max_expansions(100000)
     O.set_max_expansions(0)
     assert r["status"] == eo["status"] == A.PP_ERR_LIMIT
-    assert (r["closed"][:300] == eo["closed"][:300]).all() or r["stats"].ambiguous
+    if not (r["closed"][:300] == eo["closed"][:300]).all():
+        explained_by_guard_band(r["stats"], r["closed"], eo["closed"])
 
 
 def test_plan_batch_many_queries_on_a_large_map_vs_oracle(ctx):
@@ -175,22 +210,12 @@ def test_plan_batch_many_queries_on_a_large_map_vs_oracle(ctx):
     O.set_max_expansions(2000)
     try:
         r = api.plan_batch(ctx, m, CONF, starts, goals, cap=4096, closed_cap=2048)
-        bad = 0
+        differ = 0
         for i in range(96):
             e = om.plan(CONF, starts[i], goals[i])
-            ne = int(r["stats"][i].expansions)
-            same = (r["status"][i] == e["status"] and ne == e["stats"].expansions and
-                    (r["closed"][i, :min(ne, 2048)] == e["closed"][:2048]).all())
-            if same and e["status"] == 0:
-                L = int(r["len"][i])
-                same = (L == len(e["x"]) and abs(r["cost"][i] - e["cost"]) <= 1e-9 * abs(e["cost"]) and
-                        np.allclose(r["x"][i, :L], e["x"], rtol=1e-9, atol=1e-9) and
-                        np.allclose(r["yaw"][i, :L], e["yaw"], rtol=1e-9, atol=1e-9) and
-                        (r["dir"][i, :L] == e["dir"]).all())
-            if not same:
-                assert r["stats"][i].ambiguous, i  # only a guard-band decision may differ
-                bad += 1
-        assert bad <= 5
+            differ += not same_batch_query(r, i, e, 2048)
+        print("differing after a guard-band decision:", differ)
+        assert differ <= FLAGGED_BATCH96, differ
         assert (r["status"] == 0).sum() >= 80
     finally:
         ctx.set_max_expansions(100000)

@@ -41,6 +41,34 @@ def check_same_paths(got, exp, full=True):
             assert (np.asarray(pg["dir"]) == np.asarray(pe["dir"])).all()
 
 
+def check_flagged_pair(ctx, q0, q1, maxc, npaths_i, word_i, exp_words=None):
+    """A pair whose kernel run took a guard-band decision (accept test, duplicate test or a tie of
+    total lengths within 1e-9) is still held to this: the selected word is one of the oracle's
+    words whose total is within 1e-9 of the oracle's minimum, the path counts differ by at most
+    one, and the kernel's full word list equals the oracle's except for at most one word that is
+    present on one side only (every other word with lengths equal to 1e-9)."""
+    if exp_words is None:
+        exp_words = O.rs_words(q0, q1, maxc)
+    assert abs(int(npaths_i) - len(exp_words)) <= 1
+    tmin = min(w[2] for w in exp_words)
+    tied = [w for w in exp_words if abs(w[2] - tmin) <= RTOL * tmin]
+    assert any(w[0] == word_i.word() and np.allclose(w[1], word_i.lens(), rtol=RTOL, atol=1e-9) for w in tied)
+    assert abs(word_i.total_length - tmin) <= RTOL * tmin
+    got = api.calc_all_paths(ctx, *map(float, q0), *map(float, q1), maxc, 5.0)
+    assert len(got) == npaths_i
+
+    def find(w, pool):
+        return [k for k, p in enumerate(pool) if p[0] == w[0] and np.allclose(p[1], w[1], rtol=RTOL, atol=1e-9)]
+    gw = [(p["ctypes"], p["lengths"], p["total"]) for p in got]
+    only_got = [w for w in gw if not find(w, exp_words)]
+    only_exp = [w for w in exp_words if not find(w, gw)]
+    assert len(only_got) + len(only_exp) <= 1, (only_got, only_exp)
+    # the common words come in the same (generation) order
+    common_g = [w[0] for w in gw if find(w, exp_words)]
+    common_e = [w[0] for w in exp_words if find(w, gw)]
+    assert common_g == common_e
+
+
 def test_rs_demo_legs_golden(ctx):
     """The seven demo legs of src/main.rs:93-137.  Leg 0 ((0,0,0) -> (10,10,-90 deg), maxc 0.1)
     sits on a knife edge of the reference itself: in calc_tau_omega (reeds_shepp.rs:323-328)
@@ -54,8 +82,8 @@ def test_rs_demo_legs_golden(ctx):
         e = leg["paths"][leg["best"]]
         if flags[0] & 2:
             flagged += 1
-            a, b = [p["ctypes"] for p in got], [p["ctypes"] for p in leg["paths"]]
-            assert abs(len(a) - len(b)) <= 1 and (set(b) <= set(a) or set(a) <= set(b))
+            check_flagged_pair(ctx, leg["q0"], leg["q1"], leg["maxc"], npaths[0], words[0],
+                               [(p["ctypes"], p["lengths"], p["total"]) for p in leg["paths"]])
         else:
             check_same_paths(got, leg["paths"])
             assert bidx[0] == leg["best"]
@@ -85,6 +113,8 @@ def test_rs_random_golden_and_costs(ctx):
         e = pr["paths"][pr["best"]]
         assert abs(words[i].total_length - e["total"]) <= RTOL * e["total"]
         if not ok[i]:
+            check_flagged_pair(ctx, pr["q0"], pr["q1"], maxc, npaths[i], words[i],
+                               [(p["ctypes"], p["lengths"], p["total"]) for p in pr["paths"]])
             continue
         assert npaths[i] == len(pr["paths"]) and best[i] == pr["best"]
         e = pr["paths"][pr["best"]]
@@ -125,6 +155,12 @@ def test_rs_batch_vs_oracle_100k(ctx):
     assert np.allclose(gt[ok], et[ok], rtol=RTOL, atol=0)
     hist = np.bincount(npaths[ok])
     assert hist[6:10].sum() > 0.8 * ok.sum()
+    # flagged pairs: path counts within one of the oracle's everywhere, and the full bounded check
+    # (tied set, word lists) on every 16th of them
+    bad = np.nonzero(~ok)[0]
+    assert (np.abs(npaths[bad] - enp[bad]) <= 1).all()
+    for i in bad[::16]:
+        check_flagged_pair(ctx, q0[i], q1[i], maxc, npaths[i], words[i])
 
 
 def test_rs_all_paths_vs_oracle_random(ctx):
@@ -177,9 +213,26 @@ def test_analytic_expansion_vs_oracle(ctx):
     assert (idx[ok] == eidx[ok]).all() and (npaths[ok] == enp[ok]).all()
     assert np.allclose(cost[ok], ecost[ok], rtol=RTOL, atol=0)
     assert 5 < (efound & 1).sum() < n - 5
+    # flagged shots: the word lists differ by at most one word, and a shot that found the same
+    # path has the same cost
+    bad = np.nonzero(~ok)[0]
+    assert (np.abs(npaths[bad] - enp[bad]) <= 1).all()
+    for i in bad:
+        if (found[i] & 1) and (efound[i] & 1) and words[i].word() == ewords[i].word():
+            assert abs(cost[i] - ecost[i]) <= RTOL * ecost[i]
     for i in np.nonzero(ok & ((efound & 1) == 1))[0]:
         assert words[i].word() == ewords[i].word()
         assert np.allclose(words[i].lens(), ewords[i].lens(), rtol=RTOL, atol=1e-9)
+
+
+def test_analytic_expansion_vs_unpatched_twin_fixture(ctx):
+    """tests/golden/twin_analytic.json: analystic_expantion of the reference's Python twin on
+    pairs with pairwise distinct path costs (its queue's tie rule never applies)."""
+    from test_oracle_golden import check_analytic_fixture
+    ox, oy = W.demo_obstacles()
+    m = api.ObstacleMap(ctx, ox, oy)
+    found = check_analytic_fixture(lambda s, g: api.analytic_expansion(ctx, m, CONF, s, g))
+    assert ((found & 2) != 0).sum() <= 4
 
 
 def test_analytic_expansion_device_form_equals_host_form(ctx):

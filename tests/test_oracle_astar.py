@@ -1,9 +1,11 @@
 """CPU checks of the oracle's plain grid A* (astar_planning, astar.rs:53-132).
 
-The reference holds no output of this planner and the Python twin's open list breaks ties
-differently, so the tie rule is pinned only by restating it twice: the C++ oracle against the
-pure-Python loop below, both written from astar.rs.  The raster and grid dimensions underneath are
-pinned by the twin's fixtures (test_oracle_golden.py)."""
+Pinned by tests/golden/astar_rust.json: closing order and path from the reference's Python twin
+with its rounding and its heap's tie rule patched to the crate's (tests/golden/make_rust_semantics.py,
+group C).  The pure-Python loop below is a second restatement used on further random maps.  The
+raster and grid dimensions underneath are pinned by the twin's fixtures (test_oracle_golden.py)."""
+import json
+import os
 import heapq
 import math
 
@@ -88,6 +90,26 @@ def check_path(path, ox, oy, s, g, reso, rr):
     assert (np.abs(np.diff(cx[:-1])) <= 1).all() and (np.abs(np.diff(cy[:-1])) <= 1).all()
     assert not obs[cx[1:] - int(dims[0]), cy[1:] - int(dims[1])].any()
     return float(np.hypot(np.diff(cx[:-1]), np.diff(cy[:-1])).sum())
+
+
+def check_astar_fixture(plan):
+    """tests/golden/astar_rust.json against plan(ox, oy, sx, sy, gx, gy, reso, rr) ->
+    (status, (pathx, pathy) or None, closing order)."""
+    data = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "astar_rust.json")))
+    env = astar_env()
+    for i, q in enumerate(data):
+        ox, oy = env if q.get("map") == "astar_env" else (q["ox"], q["oy"])
+        st, path, order = plan(ox, oy, *q["s"], *q["g"], q["reso"], q["rr"])
+        assert list(order) == q["closed"], i
+        if q["path"] is None:
+            assert st == A.PP_NO_PATH and path is None, i
+        else:
+            assert st == 0 and list(path[0]) == q["path"][0] and list(path[1]) == q["path"][1], i
+    assert sum(1 for q in data if q["path"] is None) >= 2 and len(data) >= 15
+
+
+def test_against_the_patched_twin_fixture():
+    check_astar_fixture(O.astar)
 
 
 def test_demo_environment():

@@ -11,6 +11,64 @@ __device__ inline uint64_t mix(uint64_t z) {
 }
 // V: 1 = one block; 2 = blocks 0,1 of a line; 3 = blocks 0,4; 4 = two different lines;
 //    5 = blocks 0..3; 6 = blocks 0..7; 7 = 8-byte loads x1 ; 8 = 4-byte x1; 9 = 4 different lines
+// stream of three f64 arrays (HBM) + V16 gathers of 16 B from one random line per lane
+template <int V16>
+__global__ void __launch_bounds__(256) ks(uint64_t n, const uint4* __restrict__ t, uint32_t nlines, const double* __restrict__ x,
+                                          const double* __restrict__ y, const double* __restrict__ z, uint8_t* out) {
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double xv = x[i], yv = y[i], zv = z[i];
+    uint64_t h = mix(i * 0x9E3779B97F4A7C15ull + (uint64_t)(xv + yv + zv));
+    uint32_t l0 = (uint32_t)(h % nlines);
+    unsigned acc = (unsigned)h;  // keeps the stream loads alive when V16 == 0
+#pragma unroll
+    for (int b = 0; b < V16; ++b) { uint4 q = t[(size_t)l0 * 8 + b]; acc |= q.x ^ q.y ^ q.z ^ q.w; }
+    out[i] = (uint8_t)acc;
+  }
+}
+// the same with the stream loads one round ahead (PF >= 1) and the gather one round ahead (PF == 2)
+template <int V16, int PF>
+__global__ void __launch_bounds__(256) kp(uint64_t n, const uint4* __restrict__ t, uint32_t nlines, const double* __restrict__ x,
+                                          const double* __restrict__ y, const double* __restrict__ z, uint8_t* out) {
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double nx = x[i], ny = y[i], nz = z[i];
+  uint4 g[V16];
+  auto addr = [&](uint64_t k, double a, double b, double c) { return (uint32_t)(mix(k * 0x9E3779B97F4A7C15ull + (uint64_t)(a + b + c)) % nlines); };
+  if (PF == 2) {
+    uint32_t l0 = addr(i, nx, ny, nz);
+#pragma unroll
+    for (int b = 0; b < V16; ++b) g[b] = t[(size_t)l0 * 8 + b];
+    uint64_t j = i + stride;
+    if (j < n) { nx = x[j]; ny = y[j]; nz = z[j]; }
+  }
+  for (; i < n; i += stride) {
+    unsigned acc = 0;
+    if (PF == 2) {
+      uint4 c[V16];
+#pragma unroll
+      for (int b = 0; b < V16; ++b) c[b] = g[b];
+      uint64_t j = i + stride, j2 = j + stride;
+      if (j < n) {
+        uint32_t l0 = addr(j, nx, ny, nz);
+#pragma unroll
+        for (int b = 0; b < V16; ++b) g[b] = t[(size_t)l0 * 8 + b];
+        if (j2 < n) { nx = x[j2]; ny = y[j2]; nz = z[j2]; }
+      }
+#pragma unroll
+      for (int b = 0; b < V16; ++b) acc |= c[b].x ^ c[b].y ^ c[b].z ^ c[b].w;
+    } else {
+      double xv = nx, yv = ny, zv = nz;
+      uint64_t j = i + stride;
+      if (j < n) { nx = x[j]; ny = y[j]; nz = z[j]; }
+      uint32_t l0 = addr(i, xv, yv, zv);
+#pragma unroll
+      for (int b = 0; b < V16; ++b) { uint4 q = t[(size_t)l0 * 8 + b]; acc |= q.x ^ q.y ^ q.z ^ q.w; }
+    }
+    out[i] = (uint8_t)acc;
+  }
+}
 template <int V>
 __global__ void __launch_bounds__(256) k(uint64_t n, const uint4* __restrict__ t, uint32_t nlines, const double* __restrict__ x, uint8_t* out) {
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -59,6 +117,29 @@ int main() {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
     printf("%-40s %8.3f ms\n", name, ms);
   };
+  {
+    double *y, *z; CK(hipMalloc(&y, n * 8)); CK(hipMemset(y, 0, n * 8)); CK(hipMalloc(&z, n * 8)); CK(hipMemset(z, 0, n * 8));
+    uint4* t2; uint32_t nl2 = 16384; CK(hipMalloc(&t2, (size_t)nl2 * 128)); CK(hipMemset(t2, 1, (size_t)nl2 * 128));
+    auto runs = [&](auto kern, const char* name, int blocks) {
+      for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, n, t2, nl2, x, y, z, o);
+      CK(hipEventRecord(e0));
+      for (int w = 0; w < 10; ++w) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, n, t2, nl2, x, y, z, o);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+      printf("%-52s %8.3f ms\n", name, ms);
+    };
+    for (int blocks : {1024, 2048, 8192}) {
+      printf("-- 3 x f64 stream (400 MB) + gathers from a 2 MiB table, %d blocks\n", blocks);
+      runs(ks<0>, "stream only", blocks);
+      runs(ks<1>, "stream + 1 x 16B random line", blocks);
+      runs(ks<2>, "stream + 2 x 16B same line", blocks);
+      runs(ks<4>, "stream + 4 x 16B same line", blocks);
+      runs(kp<1, 1>, "stream ahead + 1 x 16B", blocks);
+      runs(kp<4, 1>, "stream ahead + 4 x 16B same line", blocks);
+      runs(kp<1, 2>, "stream and gather ahead + 1 x 16B", blocks);
+      runs(kp<4, 2>, "stream and gather ahead + 4 x 16B same line", blocks);
+    }
+  }
   run(k<0>, "no gather (8B read + 1B write)");
   run(k<8>, "1 x 4B");
   run(k<7>, "1 x 8B");

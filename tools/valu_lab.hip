@@ -26,6 +26,31 @@ template <int OP> __global__ void __launch_bounds__(256) k(float* out, int iters
       if (OP == 11) { unsigned long long x = __double_as_longlong(d[i]), y = __double_as_longlong(d[(i + 1) & 7]); d[i] = __longlong_as_double(x < y ? x : y); }
       if (OP == 12) d[i] = d[i] < d[(i + 1) & 7] ? d[i] : d[(i + 1) & 7];
       if (OP == 13) asm volatile("v_max_f64 %0, %1, %2" : "=v"(d[i]) : "v"(d[i]), "v"(d[(i + 1) & 7]));
+      if (OP == 14) asm volatile("v_cvt_u32_f32_e32 %0, %1" : "=v"(u[i]) : "v"(f[i]));
+      if (OP == 15) asm volatile("v_ceil_f32_e32 %0, %1" : "=v"(f[i]) : "v"(f[i]));
+      if (OP == 16) asm volatile("v_bfm_b32 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) & 7]));
+      if (OP == 17) asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
+      if (OP == 18) asm volatile("v_sub_u32 %0, %1, %2 clamp" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) & 7]));
+      if (OP == 19) asm volatile("v_rcp_f32_e32 %0, %1" : "=v"(f[i]) : "v"(f[i]));
+      if (OP == 20) asm volatile("v_cvt_f32_f64_e32 %0, %1" : "=v"(f[i]) : "v"(d[i]));
+      if (OP == 21) asm volatile("v_cvt_f64_f32_e32 %0, %1" : "=v"(d[i]) : "v"(f[i]));
+      if (OP == 22) asm volatile("v_rndne_f64_e32 %0, %1" : "=v"(d[i]) : "v"(d[i]));
+      if (OP == 23) asm volatile("v_cvt_i32_f64_e32 %0, %1" : "=v"(u[i]) : "v"(d[i]));
+      if (OP == 24) asm volatile("v_min3_f32 %0, %1, %2, %3" : "=v"(f[i]) : "v"(f[i]), "v"(f[(i + 1) & 7]), "v"(f[(i + 2) & 7]));
+      if (OP == 25) { unsigned long long x = __double_as_longlong(d[i]); asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(x) : "v"(u[i]), "v"(x)); d[i] = __longlong_as_double(x); }
+      if (OP == 26) asm volatile("v_bfe_u32 %0, %1, %2, %3" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
+      if (OP == 27) asm volatile("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
+      if (OP == 28) asm volatile("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(f[i]) : "v"(f[i]), "v"(f[(i + 1) & 7]) : "vcc");
+      if (OP == 29) asm volatile("v_max_u32_e32 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) & 7]));
+      if (OP == 30) asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(f[i]) : "v"(f[i]), "v"(f[(i + 1) & 7]));
+      if (OP == 31) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(p[i]) : "v"(p[i]), "v"(p[(i + 1) & 7]));
+      if (OP == 32) asm volatile("v_floor_f64_e32 %0, %1" : "=v"(d[i]) : "v"(d[i]));
+      if (OP == 33) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(d[i]) : "v"(d[i]), "v"(d[(i + 1) & 7]));
+      if (OP == 34) asm volatile("v_cvt_f32_u32_e32 %0, %1" : "=v"(f[i]) : "v"(u[i]));
+      if (OP == 35) asm volatile("v_ffbl_b32_e32 %0, %1" : "=v"(u[i]) : "v"(u[i]));
+      if (OP == 36) asm volatile("v_mov_b32_e32 %0, %1" : "=v"(u[i]) : "v"(u[(i + 1) & 7]));
+      if (OP == 37) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) & 7]));
+      if (OP == 38) asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
     }
   }
   float s = 0; for (int i = 0; i < 8; ++i) s += f[i] + (float)d[i] + (float)u[i] + p[i].x + p[i].y;
@@ -59,5 +84,30 @@ int main() {
   run(k<11>, "u64 cmp + 2 cndmask", 8);
   run(k<12>, "f64 cmp + 2 cndmask", 8);
   run(k<13>, "v_max_f64", 8);
+  run(k<14>, "v_cvt_u32_f32", 8);
+  run(k<15>, "v_ceil_f32", 8);
+  run(k<16>, "v_bfm_b32", 8);
+  run(k<17>, "v_and_or_b32", 8);
+  run(k<18>, "v_sub_u32 clamp", 8);
+  run(k<19>, "v_rcp_f32", 8);
+  run(k<20>, "v_cvt_f32_f64", 8);
+  run(k<21>, "v_cvt_f64_f32", 8);
+  run(k<22>, "v_rndne_f64", 8);
+  run(k<23>, "v_cvt_i32_f64", 8);
+  run(k<24>, "v_min3_f32", 8);
+  run(k<25>, "v_lshlrev_b64", 8);
+  run(k<26>, "v_bfe_u32", 8);
+  run(k<27>, "v_lshl_or_b32", 8);
+  run(k<28>, "v_cmp_f32 + v_cndmask", 16);
+  run(k<29>, "v_max_u32", 8);
+  run(k<30>, "v_add_f32", 8);
+  run(k<31>, "v_pk_add_f32", 8);
+  run(k<32>, "v_floor_f64", 8);
+  run(k<33>, "v_mul_f64", 8);
+  run(k<34>, "v_cvt_f32_u32", 8);
+  run(k<35>, "v_ffbl_b32", 8);
+  run(k<36>, "v_mov_b32", 8);
+  run(k<37>, "v_mul_lo_u32", 8);
+  run(k<38>, "v_mad_u32_u24", 8);
   return 0;
 }

@@ -460,8 +460,117 @@ double rs_path_cost(const double* len, const uint8_t* ct, int n, const pp_config
 
 }  // namespace
 
+// ------------------------------------------------------------------ the KD-tree form
+// The reference finds an obstacle's neighbours with the `kdtree` crate (Cargo.toml:7, pinned to
+// 0.7.0 in Cargo.lock; not vendored): `KdTree::new(2)` + `add` per obstacle (hybrid_astar.rs:136-139)
+// and `within(&[cx, cy], bound_radius, &euclid)` per pose (:426-431).  This is a restatement of that
+// crate's published algorithm, for the CPU baseline only: leaves of up to 16 points; a full leaf
+// splits on the dimension of widest bounds at the midpoint of those bounds (points below the split
+// value go left); `within` walks the tree best-first over the distance from the query to each
+// node's bounding box, keeps every point whose distance is <= radius and returns them sorted by
+// distance in a freshly allocated vector.  The flags do not depend on any of this (the radius query
+// is a pre-filter for the rectangle test), which the CPU tests check against the other two forms.
+namespace {
+class KdTree2 {
+ public:
+  void add(double px, double py, uint32_t data) {
+    if (nodes_.empty()) nodes_.emplace_back();
+    int cur = 0;
+    for (;;) {
+      Node& n = nodes_[cur];
+      n.minb[0] = std::min(n.minb[0], px);
+      n.maxb[0] = std::max(n.maxb[0], px);
+      n.minb[1] = std::min(n.minb[1], py);
+      n.maxb[1] = std::max(n.maxb[1], py);
+      ++n.size;
+      if (n.left < 0) break;
+      cur = ((n.dim == 0 ? px : py) < n.split) ? n.left : n.right;
+    }
+    nodes_[cur].pts.push_back({px, py, data});
+    if (nodes_[cur].pts.size() > kCapacity) split(cur);
+  }
+  struct Hit {
+    double dist;
+    uint32_t data;
+  };
+  // sorted by distance, as the crate returns them
+  std::vector<Hit> within(double qx, double qy, double radius) const {
+    std::vector<Hit> out;
+    if (nodes_.empty()) return out;
+    typedef std::pair<double, int> Pend;  // (distance to the node's box, node)
+    std::priority_queue<Pend, std::vector<Pend>, std::greater<Pend>> pending;
+    pending.push({0.0, 0});
+    while (!pending.empty() && pending.top().first <= radius) {
+      int cur = pending.top().second;
+      pending.pop();
+      while (nodes_[cur].left >= 0) {
+        const Node& n = nodes_[cur];
+        const bool go_left = (n.dim == 0 ? qx : qy) < n.split;
+        const int near = go_left ? n.left : n.right, far = go_left ? n.right : n.left;
+        const double d = box_distance(qx, qy, nodes_[far]);
+        if (d <= radius) pending.push({d, far});
+        cur = near;
+      }
+      for (const Pt& p : nodes_[cur].pts) {
+        const double d = std::sqrt((qx - p.x) * (qx - p.x) + (qy - p.y) * (qy - p.y));  // :428-430
+        if (d <= radius) out.push_back({d, p.data});
+      }
+    }
+    std::sort(out.begin(), out.end(), [](const Hit& a, const Hit& b) { return a.dist < b.dist; });
+    return out;
+  }
+  bool empty() const { return nodes_.empty(); }
+
+ private:
+  static constexpr size_t kCapacity = 16;
+  struct Pt {
+    double x, y;
+    uint32_t data;
+  };
+  struct Node {
+    int left = -1, right = -1, dim = 0;
+    double split = 0.0;
+    double minb[2] = {kInf, kInf}, maxb[2] = {-kInf, -kInf};
+    size_t size = 0;
+    std::vector<Pt> pts;
+  };
+  static double box_distance(double qx, double qy, const Node& n) {
+    const double cx = std::min(std::max(qx, n.minb[0]), n.maxb[0]);
+    const double cy = std::min(std::max(qy, n.minb[1]), n.maxb[1]);
+    return std::sqrt((qx - cx) * (qx - cx) + (qy - cy) * (qy - cy));
+  }
+  void split(int cur) {
+    Node& n = nodes_[cur];
+    const int dim = (n.maxb[1] - n.minb[1]) > (n.maxb[0] - n.minb[0]) ? 1 : 0;
+    if (!(n.maxb[dim] > n.minb[dim])) return;  // all points coincide (the demo map's doubled corners): stays a leaf
+    const double sv = n.minb[dim] + (n.maxb[dim] - n.minb[dim]) / 2.0;
+    std::vector<Pt> pts;
+    pts.swap(n.pts);
+    const int l = (int)nodes_.size();
+    nodes_.emplace_back();
+    nodes_.emplace_back();
+    Node& m = nodes_[cur];  // the vector may have moved
+    m.dim = dim;
+    m.split = sv;
+    m.left = l;
+    m.right = l + 1;
+    for (const Pt& p : pts) {
+      Node& c = nodes_[((dim == 0 ? p.x : p.y) < sv) ? l : l + 1];
+      c.minb[0] = std::min(c.minb[0], p.x);
+      c.maxb[0] = std::max(c.maxb[0], p.x);
+      c.minb[1] = std::min(c.minb[1], p.y);
+      c.maxb[1] = std::max(c.maxb[1], p.y);
+      ++c.size;
+      c.pts.push_back(p);
+    }
+  }
+  std::vector<Node> nodes_;
+};
+}  // namespace
+
 // ------------------------------------------------------------------ obstacle map
 struct orc_map {
+  KdTree2 kd;  // built by orc_map_create, used by mode 2 of the collision entry points
   std::vector<double> ox, oy;
   // bucket grid over unit squares: bucket (bx, by) holds the indices of points with
   // floor(x) == bx0 + bx, floor(y) == by0 + by.
@@ -484,6 +593,7 @@ orc_map* orc_map_create(const double* ox, const double* oy, uint64_t n) {
     mxy = std::max(mxy, oy[i]);
   }
   if (n == 0 || !m->finite) return m;
+  for (uint64_t i = 0; i < n; ++i) m->kd.add(ox[i], oy[i], (uint32_t)i);  // hybrid_astar.rs:136-139
   m->bx0 = (int64_t)std::floor(mnx);
   m->by0 = (int64_t)std::floor(mny);
   m->nbx = (int64_t)std::floor(mxx) - m->bx0 + 1;
@@ -568,6 +678,16 @@ inline bool pose_collides(const orc_map& m, const Footprint& f, double ix, doubl
     if (status) *status = PP_ERR_NONFINITE;
     return false;
   }
+  if (mode == 2) {  // hybrid_astar.rs:426-445 as written: radius query, then the rotated-box test per id
+    const std::vector<KdTree2::Hit> ids = m.kd.within(cx, cy, f.bound_radius);
+    for (const KdTree2::Hit& h : ids) {
+      const double xo = m.ox[h.data] - cx, yo = m.oy[h.data] - cy;
+      double dx, dy;
+      rot2d(xo, yo, -iyaw, dx, dy);  // cos and sin of -yaw once per obstacle, as util.rs:1-5 does
+      if (std::fabs(dx) < f.bound_len && std::fabs(dy) < f.bound_wid) return true;
+    }
+    return false;
+  }
   if (mode == 0 || m.nbx == 0) {
     for (size_t i = 0; i < m.ox.size(); ++i)
       if (obstacle_hits(m.ox[i], m.oy[i], cx, cy, iyaw, f)) return true;
@@ -602,6 +722,25 @@ int32_t orc_collision_flags(const orc_map* m, const pp_config* conf, uint64_t n,
   Footprint f = footprint(*conf);
   int32_t st = PP_OK;
   for (uint64_t i = 0; i < n; ++i) flags[i] = pose_collides(*m, f, x[i], y[i], yaw[i], mode, &st) ? 1 : 0;
+  return st;
+}
+
+int32_t orc_collision_flags_mt_mode(const orc_map* m, const pp_config* conf, uint64_t n, const double* x,
+                                    const double* y, const double* yaw, uint8_t* flags, int32_t threads,
+                                    int32_t mode) {
+  if (!m || !conf || (n && (!x || !y || !yaw || !flags))) return PP_ERR_INVALID;
+  if (!m->finite) return PP_ERR_NONFINITE;
+  Footprint f = footprint(*conf);
+  int32_t st = PP_OK;
+  (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : omp_get_max_threads())
+#endif
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    int32_t s = PP_OK;
+    flags[i] = pose_collides(*m, f, x[i], y[i], yaw[i], mode, &s) ? 1 : 0;
+    if (s != PP_OK) st = s;
+  }
   return st;
 }
 

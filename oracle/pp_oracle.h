@@ -44,6 +44,11 @@ int32_t orc_collision_flags(const orc_map *m, const pp_config *conf, uint64_t n,
 int32_t orc_collision_flags_mt(const orc_map *m, const pp_config *conf, uint64_t n,
                                const double *x, const double *y, const double *yaw,
                                uint8_t *flags, int32_t threads);
+/* The same with the candidate search chosen: mode 0 brute force, 1 bucket grid, 2 the KD-tree
+ * radius query + per-obstacle rot2d of hybrid_astar.rs:426-445 (the reference's own form). */
+int32_t orc_collision_flags_mt_mode(const orc_map *m, const pp_config *conf, uint64_t n,
+                                    const double *x, const double *y, const double *yaw,
+                                    uint8_t *flags, int32_t threads, int32_t mode);
 
 /* src/hybrid_astar.rs:495-514 */
 int32_t orc_motion_set(const pp_config *conf, double *steer, double *direc, uint64_t cap,

@@ -42,6 +42,7 @@ def lib():
         "orc_map_param": (C.c_int32, [vp, cfg, C.POINTER(A.Param)]),
         "orc_collision_flags": (C.c_int32, [vp, cfg, C.c_uint64, d, d, d, u8, C.c_int32]),
         "orc_collision_flags_mt": (C.c_int32, [vp, cfg, C.c_uint64, d, d, d, u8, C.c_int32]),
+        "orc_collision_flags_mt_mode": (C.c_int32, [vp, cfg, C.c_uint64, d, d, d, u8, C.c_int32, C.c_int32]),
         "orc_motion_set": (C.c_int32, [cfg, d, d, C.c_uint64, u64]),
         "orc_expand_batch": (C.c_int32, [vp, cfg, C.c_uint64, d, d, d, i64, d, d,
                                          C.POINTER(A.ExpandOut)]),
@@ -89,8 +90,8 @@ class OracleMap:
         x, y, yaw = _f64(x), _f64(y), _f64(yaw)
         flags = np.zeros(len(x), dtype=np.uint8)
         if threads:
-            st = lib().orc_collision_flags_mt(self.h, C.byref(conf), len(x), _p(x), _p(y), _p(yaw),
-                                              _p(flags, C.c_uint8), threads)
+            st = lib().orc_collision_flags_mt_mode(self.h, C.byref(conf), len(x), _p(x), _p(y), _p(yaw),
+                                                   _p(flags, C.c_uint8), threads, mode)
         else:
             st = lib().orc_collision_flags(self.h, C.byref(conf), len(x), _p(x), _p(y), _p(yaw),
                                            _p(flags, C.c_uint8), mode)

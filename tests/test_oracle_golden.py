@@ -113,19 +113,32 @@ def test_collision_flags_golden():
     ox, oy = D.demo_obstacles()
     m = O.OracleMap(ox, oy)
     poses = np.array(col["demo"]["poses"])
-    for mode in (0, 1):
+    for mode in (0, 1, 2):   # brute force, bucket grid, KD-tree radius query (the reference's form)
         st, flags = m.collision_flags(CONF, poses[:, 0], poses[:, 1], poses[:, 2], mode)
         assert st == 0
         assert flags.tolist() == col["demo"]["flags"]
     sc = col["scatter"]
     m2 = O.OracleMap(sc["ox"], sc["oy"])
     poses = np.array(sc["poses"])
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         st, flags = m2.collision_flags(CONF, poses[:, 0], poses[:, 1], poses[:, 2], mode)
         assert flags.tolist() == sc["flags"]
     st, flags = m2.collision_flags(CONF, poses[:, 0], poses[:, 1], poses[:, 2], threads=2)
     assert flags.tolist() == sc["flags"]
     assert 0.1 < np.mean(sc["flags"]) < 0.9
+
+
+def test_kdtree_form_equals_bucket_form_on_a_dense_lattice():
+    """The three candidate searches of the oracle give the same flags on the benchmark's kind of
+    map (lattice, 5 % occupied): 20 000 poses."""
+    from path_planner_amd import workloads as D
+    occ = D.occupancy_grid(256, 0.05)
+    m = O.OracleMap(*D.raster_to_points(occ))
+    x, y, yaw = D.random_poses(20000, 256)
+    _, f1 = m.collision_flags(CONF, x, y, yaw, 1)
+    _, f2 = m.collision_flags(CONF, x, y, yaw, 2)
+    _, f2t = m.collision_flags(CONF, x, y, yaw, 2, threads=4)
+    assert (f1 == f2).all() and (f2 == f2t).all() and 0.8 < f1.mean() < 0.97
 
 
 def test_collision_invariant_under_obstacle_permutation_and_duplication():

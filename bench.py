@@ -93,7 +93,7 @@ def wl_collision(args, E):
     occ = W.occupancy_grid(args.grid, 0.05)
     omap = api.ObstacleMap(E.ctx, raster=occ)
     n = args.poses
-    x, y, yaw = W.random_poses(n, args.grid, start=E.rank * n)
+    x, y, yaw = E.S.pose_shard(n, args.grid, E.rank)
     dx, dy, dyaw = (torch.from_numpy(a).to(E.dev) for a in (x, y, yaw))
     flags = torch.zeros(n, dtype=torch.uint8, device=E.dev)
     wl = SimpleNamespace(
@@ -137,7 +137,7 @@ def wl_collision(args, E):
 def wl_rs(args, E):
     torch, W = E.torch, E.W
     n = args.pairs
-    q0, q1 = W.rs_pairs(n, start=E.rank * n)
+    q0, q1 = E.S.pair_shard(n, E.rank)
     cols = [torch.from_numpy(np.ascontiguousarray(q[:, k])).to(E.dev) for q in (q0, q1) for k in range(3)]
     npaths = torch.zeros(n, dtype=torch.int32, device=E.dev)
     best = torch.zeros(n, dtype=torch.int32, device=E.dev)
@@ -176,7 +176,7 @@ def wl_expand(args, E):
     occ = W.occupancy_grid(args.grid, 0.01)
     omap = api.ObstacleMap(E.ctx, raster=occ)
     n = args.parents
-    x, y, yaw = W.random_poses(n, args.grid, start=E.rank * n)
+    x, y, yaw = E.S.pose_shard(n, args.grid, E.rank)
     steer, _ = api.calc_motion_set(E.conf)
     P = len(steer)
     dpx, dpy, dpyaw = (torch.from_numpy(a).to(E.dev) for a in (x, y, yaw))
@@ -217,7 +217,7 @@ def wl_analytic(args, E):
     occ = W.occupancy_grid(args.grid, 0.01)
     omap = api.ObstacleMap(E.ctx, raster=occ)
     n = args.pairs // 4
-    q0, q1 = W.rs_pairs(n, start=E.rank * n, extent=200.0)
+    q0, q1 = E.S.pair_shard(n, E.rank, extent=200.0)
     q0[:, :2] += args.grid / 2 - 100.0
     q1[:, :2] += args.grid / 2 - 100.0
     q6 = torch.from_numpy(np.ascontiguousarray(np.concatenate([q0.T, q1.T]))).to(E.dev)
@@ -325,7 +325,7 @@ def wl_queries(args, E):
     fg = api.collision_flags(E.ctx, omap, E.conf, cg[:, 0], cg[:, 1], cg[:, 2])
     keep = np.nonzero(inside & (fs == 0) & (fg == 0))[0][: args.queries]
     assert len(keep) == args.queries, "not enough collision-free candidates"
-    mine = keep[E.rank::E.world]
+    mine = E.S.query_shard(keep, E.rank, E.world)
     starts, goals = cs[mine], cg[mine]
     wl = SimpleNamespace(
         units=len(mine), bytes_per_unit=0.0, metric="planning_queries_per_sec", unit="queries/s",
@@ -422,6 +422,7 @@ def main():
 
     from path_planner_amd import _abi as A
     from path_planner_amd import api
+    from path_planner_amd import sharding as S
     from path_planner_amd import workloads as W
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -450,7 +451,7 @@ def main():
     conf = A.demo_config()
     if args.band > 0:
         assert ctx.lib.pp_ctx_set_relax_band(ctx.h, args.band) == 0
-    E = SimpleNamespace(torch=torch, api=api, W=W, A=A, ctx=ctx, conf=conf, dev=dev, rank=rank, world=world)
+    E = SimpleNamespace(torch=torch, api=api, W=W, A=A, S=S, ctx=ctx, conf=conf, dev=dev, rank=rank, world=world)
 
     def barrier():
         torch.cuda.synchronize()

@@ -47,6 +47,10 @@ class Context:
     def set_max_expansions(self, n):
         _chk(self.lib.pp_ctx_set_max_expansions(self.h, n), "pp_ctx_set_max_expansions")
 
+    def set_heuristic_limit(self, limit):
+        """Cost limit (cells) of plan_batch's first heuristic relaxation; negative = automatic."""
+        _chk(self.lib.pp_ctx_set_heuristic_limit(self.h, float(limit)), "pp_ctx_set_heuristic_limit")
+
     def synchronize(self):
         _chk(self.lib.pp_ctx_synchronize(self.h), "pp_ctx_synchronize")
 

@@ -31,9 +31,9 @@ extern "C" int32_t pp_ctx_create(int32_t device, void* stream, pp_ctx** out) {
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || device < 0 || device >= ndev) return PP_ERR_HIP;
+  if (hipSetDevice(device) != hipSuccess) return PP_ERR_HIP;
   pp_ctx* ctx = new pp_ctx();
   ctx->device = device;
-  PP_HIP(ctx, hipSetDevice(device));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
   if (stream) {
@@ -82,6 +82,12 @@ extern "C" int32_t pp_ctx_set_relax_band(pp_ctx* ctx, double band) {
 extern "C" int32_t pp_ctx_set_max_expansions(pp_ctx* ctx, uint64_t max_expansions) {
   if (!ctx) return PP_ERR_INVALID;
   ctx->max_expansions = max_expansions;
+  return PP_OK;
+}
+
+extern "C" int32_t pp_ctx_set_heuristic_limit(pp_ctx* ctx, double limit) {
+  if (!ctx || limit != limit) return PP_ERR_INVALID;
+  ctx->heuristic_limit = limit >= 0.0 ? limit : -1.0;
   return PP_OK;
 }
 

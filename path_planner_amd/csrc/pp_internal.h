@@ -67,6 +67,7 @@ struct pp_ctx {
   int last_hip_error = 0;
   int num_cus = 256;
   uint64_t max_expansions = 100000;  // per query, 0 = unlimited
+  double heuristic_limit = -1.0;     // cost limit of the planner's first heuristic relaxation, < 0 = automatic
   // reusable device scratch (grown on demand, never shrunk)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <queue>
 #include <thread>
@@ -286,6 +287,12 @@ class Pool {
   std::atomic<bool> stop_{false};
 };
 
+// What a context keeps between batches: the query objects and the worker threads.
+struct PlanState {
+  std::vector<Query> queries;
+  std::unique_ptr<Pool> pool;
+};
+
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 
@@ -342,10 +349,11 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   // the query objects live in the context between calls: thousands of small containers are
   // cheaper to clear than to free and allocate again
   if (!ctx->plan_state) {
-    ctx->plan_state = new std::vector<Query>();
-    ctx->plan_state_free = [](void* p) { delete (std::vector<Query>*)p; };
+    ctx->plan_state = new PlanState();
+    ctx->plan_state_free = [](void* p) { delete (PlanState*)p; };
   }
-  std::vector<Query>& Q = *(std::vector<Query>*)ctx->plan_state;
+  PlanState& state = *(PlanState*)ctx->plan_state;
+  std::vector<Query>& Q = state.queries;
   if (Q.size() < nq) Q.resize(nq);
   std::unordered_map<uint64_t, int32_t> goal_slot;
   std::vector<std::pair<uint64_t, uint64_t>> goal_cells;
@@ -415,7 +423,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     for (uint64_t i = 0; i < nq; ++i)
       if (Q[i].live) far = std::max(far, std::hypot(Q[i].start[0] - Q[i].goal[0], Q[i].start[1] - Q[i].goal[1]));
     h_limit = 2.0 * far / xyreso + 32.0;
-    if (const char* e = getenv("PP_HEURISTIC_LIMIT")) h_limit = atof(e);  // testing: any value is safe
+    if (ctx->heuristic_limit >= 0.0) h_limit = ctx->heuristic_limit;  // the caller's choice: any value is safe
     if (!(h_limit >= 0.0)) h_limit = __builtin_inf();
     st = pp_wavefront_multi_dev(ctx, hxw, hyw, (const uint8_t*)obs_buf.p, (uint32_t)ngoals, ggx.data(),
                                 ggy.data(), keep_blocked ? nullptr : (double*)hm_buf.p, al256(hcells * 8) / 8,
@@ -464,27 +472,30 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     // hmap values under the start cells: one gather for all queries
     const size_t ng = g_q.size();
     std::vector<double> hval(ng);
+    const size_t b4 = al256(ng * 4), b8 = al256(ng * 8);
+    // slots and offsets are already in the scratch buffer; read the grids where they live
+    auto gather_start_values = [&]() -> int32_t {
+      char* b = (char*)ctx->scratch;
+      const dim3 grid((unsigned)((ng + 255) / 256));
+      if (keep_blocked)
+        hipLaunchKernelGGL(k_gather_blocked, grid, dim3(256), 0, s, (uint32_t)ng, blocked, hyw, (const int32_t*)b,
+                           (const uint64_t*)(b + b4), (double*)(b + b4 + b8));
+      else
+        hipLaunchKernelGGL(k_gather_hmap, grid, dim3(256), 0, s, (uint32_t)ng, (const double* const*)tab_buf.p,
+                           (const int32_t*)b, (const uint64_t*)(b + b4), (double*)(b + b4 + b8));
+      PP_HIP(ctx, hipGetLastError());
+      PP_HIP(ctx, hipMemcpyAsync(hval.data(), b + b4 + b8, ng * 8, hipMemcpyDeviceToHost, s));
+      PP_HIP(ctx, hipStreamSynchronize(s));
+      return PP_OK;
+    };
     if (ng) {
-      const size_t b4 = al256(ng * 4), b8 = al256(ng * 8);
       st = pp_scratch_reserve(ctx, b4 + 2 * b8);
       if (st != PP_OK) return st;
       char* b = (char*)ctx->scratch;
       PP_HIP(ctx, hipMemcpyAsync(b, g_slot.data(), ng * 4, hipMemcpyHostToDevice, s));
       PP_HIP(ctx, hipMemcpyAsync(b + b4, g_off.data(), ng * 8, hipMemcpyHostToDevice, s));
-      if (keep_blocked)
-        hipLaunchKernelGGL(k_gather_blocked, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
-                           blocked, hyw, (const int32_t*)b, (const uint64_t*)(b + b4), (double*)(b + b4 + b8));
-      else
-        if (keep_blocked)
-          hipLaunchKernelGGL(k_gather_blocked, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
-                             blocked, hyw, (const int32_t*)b, (const uint64_t*)(b + b4), (double*)(b + b4 + b8));
-        else
-          hipLaunchKernelGGL(k_gather_hmap, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
-                             (const double* const*)tab_buf.p, (const int32_t*)b, (const uint64_t*)(b + b4),
-                             (double*)(b + b4 + b8));
-      PP_HIP(ctx, hipGetLastError());
-      PP_HIP(ctx, hipMemcpyAsync(hval.data(), b + b4 + b8, ng * 8, hipMemcpyDeviceToHost, s));
-      PP_HIP(ctx, hipStreamSynchronize(s));
+      st = gather_start_values();
+      if (st != PP_OK) return st;
     }
     if (h_bounded) {
       // a start cell beyond the limit (blocked cells included: the host does not hold the raster)
@@ -494,18 +505,8 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         st = pp_wavefront_multi_finish(ctx);
         if (st != PP_OK) return st;
         h_bounded = false;
-        const size_t b4 = al256(ng * 4), b8 = al256(ng * 8);
-        char* b = (char*)ctx->scratch;
-        if (keep_blocked)
-          hipLaunchKernelGGL(k_gather_blocked, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
-                             blocked, hyw, (const int32_t*)b, (const uint64_t*)(b + b4), (double*)(b + b4 + b8));
-        else
-          hipLaunchKernelGGL(k_gather_hmap, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (uint32_t)ng,
-                             (const double* const*)tab_buf.p, (const int32_t*)b, (const uint64_t*)(b + b4),
-                             (double*)(b + b4 + b8));
-        PP_HIP(ctx, hipGetLastError());
-        PP_HIP(ctx, hipMemcpyAsync(hval.data(), b + b4 + b8, ng * 8, hipMemcpyDeviceToHost, s));
-        PP_HIP(ctx, hipStreamSynchronize(s));
+        st = gather_start_values();
+        if (st != PP_OK) return st;
       }
     }
     for (size_t k = 0; k < ng; ++k) {
@@ -587,7 +588,11 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
 
   unsigned hw = std::thread::hardware_concurrency();
   unsigned workers = nq >= 128 ? std::min(15u, hw > 1 ? hw - 1 : 0u) : 0u;
-  Pool pool(workers);
+  // the worker threads are started once per context (they sleep between batches); a small batch
+  // runs on the calling thread alone
+  Pool serial(0);
+  if (workers && !state.pool) state.pool.reset(new Pool(workers));
+  Pool& pool = workers ? *state.pool : serial;
   std::vector<uint32_t> live_ids;
   live_ids.reserve(nq);
 

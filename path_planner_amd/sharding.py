@@ -1,0 +1,64 @@
+"""How the independent units of the hot path are dealt to the ranks of a multi-GPU job.
+
+Poses (collision checks), start/goal pairs (Reeds-Shepp words) and planner queries are independent
+of each other, so a rank works on its own share with no data-path collective; only results that a
+caller wants in one place are gathered.  The synthetic streams are counter-based
+(workloads.splitmix64), so rank r's share of a weak-scaling run is the slice
+[r * n, (r + 1) * n) of the one stream a single rank would draw for world * n units.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import workloads as W
+
+
+def pose_shard(n_per_rank, grid, rank):
+    """(x, y, yaw) of this rank's n_per_rank poses."""
+    return W.random_poses(n_per_rank, grid, start=rank * n_per_rank)
+
+
+def pair_shard(n_per_rank, rank, extent=100.0):
+    """(q0[n,3], q1[n,3]) of this rank's n_per_rank start/goal pairs."""
+    return W.rs_pairs(n_per_rank, start=rank * n_per_rank, extent=extent)
+
+
+def query_shard(ids, rank, world):
+    """This rank's share of a fixed list of queries: dealt round-robin, so long and short
+    queries (the list is ordered by goal) spread evenly."""
+    return ids[rank::world]
+
+
+def gather_slices(part, rank, world, group=None):
+    """Rank 0 gets the ranks' arrays (equal dtype and trailing shape) joined in rank order -- the
+    inverse of pose_shard / pair_shard.  Other ranks get None."""
+    part = np.ascontiguousarray(part)
+    if world == 1:
+        return part
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(part, parts, dst=0, group=group)
+    return np.concatenate(parts, axis=0) if rank == 0 else None
+
+
+def gather_dealt(part, rank, world, total, group=None):
+    """Rank 0 gets the per-query rows back in the order of the undealt list -- the inverse of
+    query_shard.  Other ranks get None."""
+    part = np.ascontiguousarray(part)
+    if world == 1:
+        return part
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(part, parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = np.empty((total,) + part.shape[1:], dtype=part.dtype)
+    for r, p in enumerate(parts):
+        out[r::world] = p
+    return out
+
+
+def sum_over_ranks(value, device, group=None):
+    """All-reduce (SUM) of one number -- the only collective of a sharded run, for its totals."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item())

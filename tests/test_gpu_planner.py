@@ -2,7 +2,6 @@
 grid indices bit-exact, path cost / coordinates to 1e-9 relative."""
 import ctypes as C
 import math
-import os
 
 import numpy as np
 import pytest
@@ -224,8 +223,8 @@ def test_plan_batch_many_queries_on_a_large_map_vs_oracle(ctx):
 
 def test_bounded_heuristic_grids_do_not_change_a_search(ctx):
     """The planner relaxes its heuristic grids only up to a cost limit and completes them when a
-    search looks beyond it.  Whatever the limit (PP_HEURISTIC_LIMIT overrides the planner's own
-    choice), closing order, counters and paths are those of the run on complete grids."""
+    search looks beyond it.  Whatever the limit (pp_ctx_set_heuristic_limit overrides the planner's
+    own choice), closing order, counters and paths are those of the run on complete grids."""
     occ = W.plan_map(1024)
     m = api.ObstacleMap(ctx, raster=occ)
     cs, cg = W.plan_queries(300, 1024, 6)
@@ -237,19 +236,16 @@ def test_bounded_heuristic_grids_do_not_change_a_search(ctx):
     ctx.set_max_expansions(1500)
     runs = {}
     try:
-        for lim in ("inf", None, "40", "3", "0"):
-            if lim is None:
-                os.environ.pop("PP_HEURISTIC_LIMIT", None)
-            else:
-                os.environ["PP_HEURISTIC_LIMIT"] = lim
+        for lim in (float("inf"), None, 40.0, 3.0, 0.0):
+            ctx.set_heuristic_limit(-1.0 if lim is None else lim)
             r = api.plan_batch(ctx, m, CONF, starts, goals, cap=4096, closed_cap=1500)
             runs[lim] = {k: np.array(r[k], copy=True) for k in ("status", "len", "cost", "x", "y", "yaw", "dir", "closed")}
             runs[lim]["exp"] = np.array([int(s.expansions) for s in r["stats"]])
             runs[lim]["poses"] = np.array([int(s.poses_checked) for s in r["stats"]])
     finally:
-        os.environ.pop("PP_HEURISTIC_LIMIT", None)
+        ctx.set_heuristic_limit(-1.0)
         ctx.set_max_expansions(100000)
-    ref = runs["inf"]
+    ref = runs[float("inf")]
     assert (ref["status"] == 0).sum() >= 50 and ref["exp"].max() > 20
     for lim, r in runs.items():
         for k, v in ref.items():

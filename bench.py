@@ -67,6 +67,8 @@ def parse():
                     help="queries workload: obstacle density 0.035 and starts 100-400 m from the goal "
                          "(the median query closes about a hundred nodes)")
     ap.add_argument("--band", type=float, default=0.0, help="relaxation band override (wavefront)")
+    ap.add_argument("--slab-band", type=float, default=1024.0,
+                    help="multi-GPU wavefront: cost band the ranks advance by per exchange round")
     ap.add_argument("--map-kind", default="bernoulli", choices=["bernoulli", "walls"],
                     help="wavefront obstacle raster: Bernoulli(0.2) or long walls with one gap each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -272,13 +274,14 @@ def wl_wavefront(args, E):
         rounds = None
     else:
         obs_s, cost = tiled.make_slab(obs_np, ncell, ncell, x0, x1, E.dev)
-        solver = tiled.DeviceSlabSolver(E.ctx, ncell, ncell, x0, x1, obs_s, cost, (gx, gy))
         rounds = []
+        solver = tiled.DeviceSlabSolver(E.ctx, ncell, ncell, x0, x1, obs_s, (gx, gy))
 
         def step():
-            cost.fill_(float("inf"))
-            torch.cuda.synchronize()
-            rounds.append(tiled.tiled_wavefront(solver, E.rank, E.world))
+            # packing the raster and writing the dense slab are part of the job, as they are on one GPU
+            solver.reset(obs_s)
+            rounds.append(tiled.tiled_wavefront(solver, E.rank, E.world, band=args.slab_band))
+            solver.read(cost)
         wl.step = step
 
     def finish(out):

@@ -155,6 +155,12 @@ def load_library(path=None):
         "pp_wavefront_slab_dev": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                               vp, vp, C.c_int32, C.c_uint64, C.c_uint64, vp, vp,
                                               i32, i32, u64]),
+        "pp_slab_create": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp, C.c_uint64,
+                                       C.c_uint64, C.POINTER(vp)]),
+        "pp_slab_relax": (C.c_int32, [vp, vp, vp, C.c_double, vp, vp, d, u64]),
+        "pp_slab_read": (C.c_int32, [vp, vp]),
+        "pp_slab_reset": (C.c_int32, [vp, vp]),
+        "pp_slab_destroy": (None, [vp]),
         "pp_rs_batch": (C.c_int32, [vp, C.c_uint64, d, d, d, d, d, d, C.c_double, i32, i32,
                                     C.POINTER(RsWord), u8]),
         "pp_rs_batch_dev": (C.c_int32, [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_double, vp, vp,

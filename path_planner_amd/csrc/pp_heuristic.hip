@@ -627,6 +627,53 @@ __global__ void k_take_halo(DenseView d, TileGrid g, TileWork w, const double* _
   }
 }
 
+// The same for a slab whose working copy stays in the blocked layout between calls: the halo
+// columns are stored columns col_lo / col_hi of the blocked array, and `round` is the next round to
+// run (its list kernel reads minkey[round % 3]).
+__global__ void k_slab_take_halo(TileGrid g, TileWork w, uint64_t yw, uint64_t col_lo, uint64_t col_hi,
+                                 const double* __restrict__ lo_new, const double* __restrict__ hi_new,
+                                 uint32_t round) {
+  const uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (y >= yw) return;
+  for (int side = 0; side < 2; ++side) {
+    const double* src = side ? hi_new : lo_new;
+    if (!src) continue;
+    const uint64_t col = side ? col_hi : col_lo;
+    const uint32_t t = (uint32_t)(col >> 5) * g.nty + (uint32_t)(y >> 5);
+    const uint32_t lx = (uint32_t)col & 31u, ly = (uint32_t)y & 31u;
+    double* cell = g.blk + (uint64_t)t * kBlk + blk_off((lx & 3u) * 4u + (ly & 3u), (lx >> 2) * 8u + (ly >> 2));
+    const double v = src[y];
+    if (v < *cell) {
+      *cell = v;
+      const unsigned long long kb = (unsigned long long)__double_as_longlong(v);
+      for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int64_t nx = (int64_t)col + dx, ny = (int64_t)y + dy;
+          if (nx >= 0 && ny >= 0) tile_wake(g, w, nx >> 6, ny >> 6, kb);
+        }
+      atomicMin(&w.minkey[round % 3], kb);
+    }
+  }
+}
+
+// First and last owned column of a slab, blocked -> the neighbours' halo buffers.  edge_lo / edge_hi
+// hold what was handed out before; *moved_min receives the lowest value that is new.
+__global__ void k_slab_edges(TileGrid g, uint64_t yw, uint64_t col_first, uint64_t col_last,
+                             double* __restrict__ edge_lo, double* __restrict__ edge_hi,
+                             unsigned long long* moved_min) {
+  const uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (y >= yw) return;
+  for (int side = 0; side < 2; ++side) {
+    double* dst = side ? edge_hi : edge_lo;
+    if (!dst) continue;
+    const double v = tile_cell_value(g, (int64_t)(side ? col_last : col_first), (int64_t)y);
+    if (v < dst[y]) {
+      dst[y] = v;
+      atomicMin(moved_min, (unsigned long long)__double_as_longlong(v));
+    }
+  }
+}
+
 struct TileRun {
   TileGrid g{};
   TileWork w{};
@@ -648,8 +695,11 @@ void wave_resume_drop(pp_ctx* ctx) {
 
 // Blocked costs, masks and work lists live in a context-owned buffer (grown on demand) so
 // repeated calls do not allocate.
-int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run) {
-  wave_resume_drop(ctx);  // the buffer is about to be overwritten
+int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run, void** own_buf = nullptr,
+                     size_t* own_bytes = nullptr) {
+  void*& wbuf = own_buf ? *own_buf : ctx->wave_buf;
+  size_t& wbytes = own_bytes ? *own_bytes : ctx->wave_bytes;
+  if (!own_buf) wave_resume_drop(ctx);  // the context's buffer is about to be overwritten
   const uint64_t ntx = (d.ncols + kTile - 1) / kTile, nty = (d.yw + kTile - 1) / kTile;
   const uint64_t nblocks = ntx * nty;
   const uint64_t nsx = (ntx + 1) / 2, nsy = (nty + 1) / 2, ntiles = nsx * nsy;  // scheduling tiles
@@ -658,14 +708,14 @@ int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run) {
   const size_t b_blk = al(nblocks * kBlk * 8), b_mask = al(nblocks * 64 * 4), b_list = al(ntiles * 4);
   const size_t b_bits = al(((ntiles + 63) / 64) * 8), b_key = al(ntiles * 8), b_misc = 256;
   const size_t need = b_blk + b_mask + b_list + b_bits + b_key + b_misc;
-  if (need > ctx->wave_bytes) {
-    if (ctx->wave_buf) PP_HIP(ctx, hipFree(ctx->wave_buf));
-    ctx->wave_buf = nullptr;
-    ctx->wave_bytes = 0;
-    PP_HIP(ctx, hipMalloc(&ctx->wave_buf, need));
-    ctx->wave_bytes = need;
+  if (need > wbytes) {
+    if (wbuf) PP_HIP(ctx, hipFree(wbuf));
+    wbuf = nullptr;
+    wbytes = 0;
+    PP_HIP(ctx, hipMalloc(&wbuf, need));
+    wbytes = need;
   }
-  char* b = (char*)ctx->wave_buf;
+  char* b = (char*)wbuf;
   run->g.blk = (double*)b;
   b += b_blk;
   run->g.mask = (uint32_t*)b;
@@ -706,7 +756,7 @@ int32_t tile_run(pp_ctx* ctx, TileRun& run, uint64_t* rounds_out, uint32_t statu
   const unsigned lgrid = (run.w.ntiles + 255) / 256;
   uint32_t round = run.round;
   uint32_t counts[3];
-  uint32_t batch = 8;
+  uint32_t batch = 2;  // a slab session often has a round or two of work per call
   for (;;) {
     for (uint32_t j = 0; j < batch; ++j, ++round) {
       hipLaunchKernelGGL(k_tile_list, dim3(lgrid), dim3(256), 0, ctx->stream, run.g, run.w, round);
@@ -888,6 +938,116 @@ extern "C" int32_t pp_wavefront_slab_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, 
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (changed_lo) *changed_lo = (int32_t)status[2];
   if (changed_hi) *changed_hi = (int32_t)status[3];
+  return PP_OK;
+}
+
+// ------------------------------------------------------------------ slab sessions
+// A slab whose blocked working copy lives from pp_slab_create to pp_slab_destroy: the raster is
+// packed once, every pp_slab_relax continues from the state the last one left, and the dense costs
+// are written only when asked for.
+struct pp_slab {
+  pp_ctx* ctx = nullptr;
+  TileRun run;
+  DenseView d{};
+  unsigned sg = 0;
+  void* buf = nullptr;
+  size_t bytes = 0;
+  unsigned long long* moved_min = nullptr;  // device word inside buf
+};
+
+extern "C" int32_t pp_slab_reset(pp_slab* s, const uint8_t* d_obs_slab);
+
+extern "C" int32_t pp_slab_create(pp_ctx* ctx, uint64_t xw, uint64_t yw, uint64_t x_begin, uint64_t x_end,
+                                  const uint8_t* d_obs_slab, uint64_t goal_x, uint64_t goal_y, pp_slab** out) {
+  if (!ctx || !d_obs_slab || !out) return PP_ERR_INVALID;
+  *out = nullptr;
+  if (x_begin >= x_end || x_end > xw) return PP_ERR_INVALID;
+  if (yw == 0 || xw >= ((uint64_t)1 << 31) || yw >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
+  if (goal_x >= xw || goal_y >= yw) return PP_ERR_BOUNDS;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t ncols = x_end - x_begin + 2;
+  const bool goal_owned = goal_x >= x_begin && goal_x < x_end;
+  pp_slab* s = new pp_slab();
+  s->ctx = ctx;
+  s->d = DenseView{nullptr, d_obs_slab, yw, ncols, (int64_t)x_begin - 1, 1, ncols - 1,
+                   goal_owned ? (int64_t)(goal_x - x_begin + 1) : -1, goal_owned ? (int64_t)goal_y : -1,
+                   0, 0, 0, nullptr};
+  int32_t st = pp_slab_reset(s, d_obs_slab);
+  if (st != PP_OK) {
+    if (s->buf) (void)hipFree(s->buf);
+    delete s;
+    return st;
+  }
+  *out = s;
+  return PP_OK;
+}
+
+extern "C" int32_t pp_slab_reset(pp_slab* s, const uint8_t* d_obs_slab) {
+  if (!s || !d_obs_slab) return PP_ERR_INVALID;
+  pp_ctx* ctx = s->ctx;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  s->d.obs = d_obs_slab;
+  s->run = TileRun{};
+  int32_t st = tile_prepare(ctx, s->d, &s->run, &s->buf, &s->bytes);
+  if (st != PP_OK) return st;
+  s->moved_min = (unsigned long long*)((char*)s->run.w.count + 192);
+  s->sg = tile_stream_grid(ctx, s->run.nblocks);
+  hipLaunchKernelGGL(k_tile_pack, dim3(s->sg), dim3(256), 0, ctx->stream, s->d, s->run.g, s->run.nblocks, 1);
+  if (s->d.goal_x >= 0)
+    hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, s->run.g, s->run.w, s->d.goal_x, s->d.goal_y);
+  PP_HIP(ctx, hipGetLastError());
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the raster may be released after the call
+  return PP_OK;
+}
+
+extern "C" void pp_slab_destroy(pp_slab* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->ctx->device);
+  (void)hipStreamSynchronize(s->ctx->stream);
+  if (s->buf) (void)hipFree(s->buf);
+  delete s;
+}
+
+extern "C" int32_t pp_slab_relax(pp_slab* s, const double* d_halo_lo_new, const double* d_halo_hi_new,
+                                 double limit, double* d_edge_lo, double* d_edge_hi, double* pending,
+                                 uint64_t* iters) {
+  if (!s || limit != limit) return PP_ERR_INVALID;
+  pp_ctx* ctx = s->ctx;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t yw = s->d.yw;
+  const unsigned yg = (unsigned)((yw + 255) / 256);
+  if (d_halo_lo_new || d_halo_hi_new)
+    hipLaunchKernelGGL(k_slab_take_halo, dim3(yg), dim3(256), 0, ctx->stream, s->run.g, s->run.w, yw,
+                       (uint64_t)0, s->d.ncols - 1, d_halo_lo_new, d_halo_hi_new, s->run.round);
+  s->run.w.limit = limit;
+  const uint64_t round0 = s->run.round;
+  uint64_t rounds = 0;
+  uint32_t status[4];
+  int32_t st = tile_run(ctx, s->run, &rounds, status);
+  if (st != PP_OK) return st;
+  hipLaunchKernelGGL(k_fill_inf, dim3(1), dim3(64), 0, ctx->stream, (double*)s->moved_min, (uint64_t)1);
+  hipLaunchKernelGGL(k_slab_edges, dim3(yg), dim3(256), 0, ctx->stream, s->run.g, yw, (uint64_t)1, s->d.ncols - 2,
+                     d_edge_lo, d_edge_hi, s->moved_min);
+  PP_HIP(ctx, hipGetLastError());
+  // what is left: tiles woken above the limit, and edge values the neighbours have not seen yet
+  double left[2];
+  PP_HIP(ctx, hipMemcpyAsync(&left[0], s->run.w.minkey + s->run.round % 3, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PP_HIP(ctx, hipMemcpyAsync(&left[1], s->moved_min, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (pending) *pending = std::min(left[0], left[1]);
+  if (iters) *iters = rounds - round0;
+  return PP_OK;
+}
+
+extern "C" int32_t pp_slab_read(pp_slab* s, double* d_cost_slab) {
+  if (!s || !d_cost_slab) return PP_ERR_INVALID;
+  pp_ctx* ctx = s->ctx;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  DenseView d = s->d;
+  d.cost = d_cost_slab;
+  hipLaunchKernelGGL(k_tile_unpack, dim3(s->sg), dim3(256), 0, ctx->stream, d, s->run.g, s->run.nblocks);
+  PP_HIP(ctx, hipGetLastError());
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PP_OK;
 }
 

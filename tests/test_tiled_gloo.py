@@ -46,6 +46,8 @@ def test_slab_bounds_cover_the_grid():
     (3, ["--xw", "50", "--yw", "33", "--density", "0.3", "--seed", "9"]),
     (2, ["--density", "0.0", "--xw", "48", "--yw", "30"]),          # walls: many exchange rounds
     (2, ["--goal", "1", "1", "--xw", "40", "--yw", "40", "--density", "0.15"]),
+    (3, ["--band", "1.0", "--xw", "45", "--yw", "31"]),            # a band below one diagonal step
+    (2, ["--band", "1e9", "--density", "0.0", "--xw", "48", "--yw", "30"]),  # every slab to its fixpoint
 ])
 def test_tiled_protocol_gloo_host_solver(world, extra):
     out = _run(world, "--mode", "host", *extra)
@@ -56,6 +58,7 @@ def test_tiled_protocol_gloo_host_solver(world, extra):
 @pytest.mark.parametrize("world,extra", [
     (2, ["--xw", "300", "--yw", "257", "--density", "0.25"]),
     (3, ["--xw", "200", "--yw", "190", "--density", "0.0"]),
+    (2, ["--xw", "700", "--yw", "300", "--density", "0.2", "--band", "64"]),
 ])
 def test_tiled_slab_kernel_device(world, extra):
     _run(world, "--mode", "device", *extra)

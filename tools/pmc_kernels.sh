@@ -18,7 +18,7 @@ for p in sys.argv[2:]:
     f=sorted(glob.glob(f"{O}/{d}/*/*counter_collection.csv"), key=os.path.getmtime)[-1]
     acc=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        k=r["Kernel_Name"].split("(")[0].replace("void ","")
+        k=r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0].replace("void ","")
         if k.startswith("at::") or "elementwise" in k: continue
         acc[(k,r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k,c),v in sorted(acc.items()): print(f"{d:8s} {k[:60]:60s} {c:28s} launches {len(v):5d} mean {sum(v)/len(v):16.1f} sum {sum(v):18.1f}")

@@ -1,14 +1,13 @@
 // pp_heuristic.hip -- holonomic heuristic: obstacle raster (calc_obsmap, astar.rs:244-261) and
-// cost-to-go grid (the Dijkstra of astar.rs:153-198) as a bucketed wavefront relaxation.
+// cost-to-go grid (the Dijkstra of astar.rs:153-198) as a tiled relaxation.
 //
 // The cost-to-go is the unique fixpoint d[v] = min over valid neighbours n of fl(d[n] + w),
 // w in {1, hypot(1,1)}, d[goal] = 0: every addition the serial Dijkstra performs along a
 // shortest path is performed here too, in fp64, and min is order-free, so the grid is
-// bit-identical to the reference's whatever the schedule.  Edge weights are >= 1, hence every
-// cell whose cost lies in [k, k+1) is final once all cells below k have been expanded
-// (fl(c + w) >= k + 1 for c >= k): the wavefront processes unit-width cost buckets in order,
-// each cell expanded once with its final cost.  Relaxations are 64-bit atomic min on the cost
-// bits (non-negative doubles order like unsigned integers).
+// bit-identical to the reference's whatever the schedule.  The schedule here: 64x64-cell tiles
+// relaxed by one workgroup each (register patches, chamfer sweeps, rims traded through LDS), in
+// rounds ordered by the lowest value waiting at each tile.
+#include <cstdio>
 #include <algorithm>
 
 #include "pp_internal.h"
@@ -336,12 +335,28 @@ __global__ void __launch_bounds__(256) k_tile_list(TileGrid g, TileWork w, uint3
 // barriers each) until no cell of the tile moves.
 constexpr int kSPps = 2 * kPps;              // patches per scheduling-tile side
 constexpr int kSRing = kSPps + 2;
-constexpr int kSSlot = kSRing * kSRing;      // doubles per rim slot
+#ifndef PP_LDS_STRIDE
+#define PP_LDS_STRIDE 24
+#endif
+constexpr int kSRow = PP_LDS_STRIDE;         // doubles from one patch row to the next in a rim slot
+constexpr int kSSlot = kSRing * kSRow;       // doubles per rim slot
 constexpr int kSTile = 2 * kTile;
-constexpr uint32_t kSweepCap = 12;           // sweeps per visit (the mean visit takes 10.6)
+#ifndef PP_SWEEP_CAP
+#define PP_SWEEP_CAP 12
+#endif
+constexpr uint32_t kSweepCap = PP_SWEEP_CAP;  // sweeps per visit (the mean visit takes 10.6)
+#ifndef PP_CAP_MIN_TILES
+#define PP_CAP_MIN_TILES 64
+#endif
+#ifndef PP_TILE_WAVES
+#define PP_TILE_WAVES 3                      // waves per SIMD the register allocation of k_tile_round aims at
+#endif
+#ifndef PP_TILE_GRID
+#define PP_TILE_GRID 4                       // workgroups per CU in a round's launch
+#endif
 
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, PP_TILE_WAVES)
 k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
   __shared__ double lds[12 * kSSlot];
   __shared__ uint32_t edge_bits;                 // which edges / corners of the tile moved
@@ -351,12 +366,21 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const int qx = (int)(wv >> 1), qy = (int)(wv & 1u);
   const uint32_t n = w.count[round % 3];
+  // sweeps per visit: a round with many tiles is cut at its slowest ones, a round with a handful of
+  // tiles (a front threading a corridor) gains nothing from that and relaxes them to the end
+  const uint32_t cap = n >= PP_CAP_MIN_TILES ? kSweepCap : 0xFFFFFFFFu;
   const int px = (int)(lane >> 3), py = (int)(lane & 7u);
   const double INF = __longlong_as_double((long long)kInfBits);
-  const int own_slot = (qx * kPps + px + 1) * kSRing + (qy * kPps + py + 1);
+  const int own_slot = (qx * kPps + px + 1) * kSRow + (qy * kPps + py + 1);
   unsigned long long blk_min = kInfBits;  // lowest key this workgroup handed out (thread 0)
   uint32_t visits = 0, sweeps_total = 0;
 
+#ifdef PP_LAB_PHASES
+  unsigned long long ph[4] = {0, 0, 0, 0}, t0 = wall_clock64(), t1;
+#define PP_PHASE(k) do { t1 = wall_clock64(); ph[k] += t1 - t0; t0 = t1; } while (0)
+#else
+#define PP_PHASE(k) do { } while (0)
+#endif
   for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
     const uint32_t t = w.list[it];
     const uint32_t tx = t / g.nsy, ty = t - tx * g.nsy;
@@ -402,21 +426,22 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
         const int side = r >= kSTile + 2, o = (side ? r - (kSTile + 2) : r) - 1;  // o = -1 .. 64
         const int q = (o + 4) >> 2, j = (o + 4) & 3;
         if (!side)
-          lds[(4 + j) * kSSlot + 0 * kSRing + q] = tile_cell_value(g, X0 - 1, Y0 + o);                // slot (3, j)
+          lds[(4 + j) * kSSlot + 0 * kSRow + q] = tile_cell_value(g, X0 - 1, Y0 + o);                // slot (3, j)
         else
-          lds[j * kSSlot + (kSRing - 1) * kSRing + q] = tile_cell_value(g, X0 + kSTile, Y0 + o);      // slot (0, j)
+          lds[j * kSSlot + (kSRing - 1) * kSRow + q] = tile_cell_value(g, X0 + kSTile, Y0 + o);      // slot (0, j)
       } else {
         const int rr = r - 2 * (kSTile + 2);
         const int side = rr >= kSTile, o = side ? rr - kSTile : rr;  // o = 0 .. 63
         const int prow = (o >> 2) + 1, i = o & 3;
         const int s3 = i == 0 ? 3 : (i == 3 ? 7 : 9 + i), s0 = i == 0 ? 0 : (i == 3 ? 4 : 7 + i);
         if (!side)
-          lds[s3 * kSSlot + prow * kSRing + 0] = tile_cell_value(g, X0 + o, Y0 - 1);                  // slot (i, 3)
+          lds[s3 * kSSlot + prow * kSRow + 0] = tile_cell_value(g, X0 + o, Y0 - 1);                  // slot (i, 3)
         else
-          lds[s0 * kSSlot + prow * kSRing + (kSRing - 1)] = tile_cell_value(g, X0 + o, Y0 + kSTile);  // slot (i, 0)
+          lds[s0 * kSSlot + prow * kSRow + (kSRing - 1)] = tile_cell_value(g, X0 + o, Y0 + kSTile);  // slot (i, 0)
       }
     }
     __syncthreads();
+    PP_PHASE(0);
 
     // A wave sits a sweep out when nothing it reads has changed since its last one: none of its
     // own lanes moved and no neighbouring wave moved a patch on the shared edge.
@@ -426,6 +451,7 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
     // sweep: any mix of old and new values is a state the relaxation may pass through (an 8-byte
     // LDS access is not torn), and the loop only ends after a sweep in which nobody wrote.
     uint32_t sweeps = 0, todo = 0xFu;
+    bool moved_any = false;  // this lane's patch changed in some sweep of the visit
     for (;;) {
       const bool active = (todo >> wv) & 1u;
       const uint32_t nxt = (sweeps + 1u) % 3u;
@@ -438,7 +464,7 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
             if (ii >= 1 && ii <= 4 && jj >= 1 && jj <= 4) continue;
             const int dx = ii == 0 ? -1 : (ii == 5 ? 1 : 0), dy = jj == 0 ? -1 : (jj == 5 ? 1 : 0);
             const int si = ii == 0 ? 3 : (ii == 5 ? 0 : ii - 1), sj = jj == 0 ? 3 : (jj == 5 ? 0 : jj - 1);
-            e[ii][jj] = lds[rim_slot(si, sj) * kSSlot + own_slot + dx * kSRing + dy];
+            e[ii][jj] = lds[rim_slot(si, sj) * kSSlot + own_slot + dx * kSRow + dy];
           }
         }
         bool moved = false;  // values only ever go down
@@ -470,6 +496,7 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
             e[i][j] = v;
           }
         }
+        moved_any |= moved;
         if (moved) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -491,7 +518,7 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
       __syncthreads();  // rims and the activity word are published
       todo = act[nxt];
       if (todo == 0) break;
-      if (sweeps >= kSweepCap) {
+      if (sweeps >= cap) {
         // A front that winds through the tile needs many sweeps, and the round lasts as long as
         // its slowest tile.  Such a tile stops here and wakes itself, with the lowest value of the
         // waves that still had work as its key, so the round ends and the rest of the front moves
@@ -509,10 +536,11 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
       }
     }
 
+    PP_PHASE(1);
     // write back what moved; cells on the tile's edge wake the neighbours that read them
     uint32_t bits = 0;  // 0 x-lo, 1 x-hi, 2 y-lo, 3 y-hi, 4..7 corners (00, 01, 10, 11), 8 first col, 9 last col
     double edge_min = INF;
-    if (have) {
+    if (have && moved_any) {  // a patch that never moved is not read back
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) {
         double2* p = (double2*)(blk + blk_off(2 * k2, lane));
@@ -567,7 +595,14 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
       sweeps_total += sweeps;
     }
     __syncthreads();  // edge_bits / edge_key and the LDS rims are reused by the next tile
+    PP_PHASE(2);
   }
+#ifdef PP_LAB_PHASES
+  if (tid == 0 && visits) {
+    unsigned long long* prof = (unsigned long long*)((char*)w.count + 208);
+    for (int k = 0; k < 3; ++k) atomicAdd(&prof[k], ph[k]);
+  }
+#endif
   if (tid == 0 && visits) {
     if (blk_min != kInfBits) atomicMin(&w.minkey[(round + 1) % 3], blk_min);
     atomicAdd(&w.status[0], visits);
@@ -740,7 +775,7 @@ int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run, void** own_b
   run->w.own_first = d.own_lo;
   run->w.own_last = d.own_hi - 1;
   PP_HIP(ctx, hipMemsetAsync(run->w.bitmap, 0, b_bits, ctx->stream));
-  PP_HIP(ctx, hipMemsetAsync(run->w.count, 0, 128, ctx->stream));
+  PP_HIP(ctx, hipMemsetAsync(run->w.count, 0, 256, ctx->stream));
   // keys and minkey[3] start at +inf
   hipLaunchKernelGGL(k_fill_inf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, (double*)run->w.key,
                      (uint64_t)ntiles);
@@ -752,7 +787,7 @@ int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run, void** own_b
 // round over an empty list costs two empty launches.
 int32_t tile_run(pp_ctx* ctx, TileRun& run, uint64_t* rounds_out, uint32_t status_out[4]) {
   const double diag = std::hypot(1.0, 1.0);  // u_cost((+-1, +-1)), astar.rs:213-215
-  const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus * 4, run.w.ntiles);
+  const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus * PP_TILE_GRID, run.w.ntiles);
   const unsigned lgrid = (run.w.ntiles + 255) / 256;
   uint32_t round = run.round;
   uint32_t counts[3];
@@ -771,6 +806,14 @@ int32_t tile_run(pp_ctx* ctx, TileRun& run, uint64_t* rounds_out, uint32_t statu
   }
   PP_HIP(ctx, hipMemcpyAsync(status_out, run.w.status, 16, hipMemcpyDeviceToHost, ctx->stream));
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+#ifdef PP_LAB_PHASES
+  {
+    unsigned long long prof[3];
+    PP_HIP(ctx, hipMemcpy(prof, (char*)run.w.count + 208, 24, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[phases] %u visits: load %.2f sweeps %.2f store+wake %.2f us per visit\n", status_out[0],
+            prof[0] / 100.0 / status_out[0], prof[1] / 100.0 / status_out[0], prof[2] / 100.0 / status_out[0]);
+  }
+#endif
   run.round = round;
   if (rounds_out) *rounds_out = round;
   ctx->wave_stats[0] = round;

@@ -528,7 +528,13 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   // ---- device / pinned staging for the rounds
   // a round expands one node per live query, plus nodes near the top of the open list while few
   // queries are left (kSpecItems in all, at most kSpecDepth per query)
-  constexpr size_t kSpecItems = 128, kSpecDepth = 8, kCacheMax = 256;
+#ifndef PP_SPEC_ITEMS
+#define PP_SPEC_ITEMS 128
+#endif
+#ifndef PP_SPEC_DEPTH
+#define PP_SPEC_DEPTH 8
+#endif
+  constexpr size_t kSpecItems = PP_SPEC_ITEMS, kSpecDepth = PP_SPEC_DEPTH, kCacheMax = 256;
   constexpr size_t kRoundFusedMax = 1024;  // nodes; below this a round is one launch
   constexpr size_t kRoundDirectMax = 128;  // nodes; below this the kernels work on the pinned staging area
   const size_t B = std::max<size_t>(nq, kSpecItems + kSpecDepth);

@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--band", type=float, default=0.0, help="relaxation band override (wavefront)")
     ap.add_argument("--slab-band", type=float, default=1024.0,
                     help="multi-GPU wavefront: cost band the ranks advance by per exchange round")
+    ap.add_argument("--car", default="demo", choices=["demo", "compact"],
+                    help="collision workload: the reference's demo car (bounding radius 5.06 cells) or a "
+                         "4.0 x 1.8 m car (radius 2.46 cells: the filter's eight-row window)")
     ap.add_argument("--map-kind", default="bernoulli", choices=["bernoulli", "walls"],
                     help="wavefront obstacle raster: Bernoulli(0.2) or long walls with one gap each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,9 +103,10 @@ def wl_collision(args, E):
     flags = torch.zeros(n, dtype=torch.uint8, device=E.dev)
     wl = SimpleNamespace(
         units=n, bytes_per_unit=BYTES_PER_POSE, metric="collision_checked_poses_per_sec", unit="poses/s",
-        scaling="weak", dtype="f64", kernel="k_collision", bound="hbm", counters_key="collision",
+        scaling="weak", dtype="f64", kernel="k_collision", bound="hbm",
+        counters_key="collision" if args.car == "demo" else None,
         config={"workload": f"footprint collision, {n} SE(2) poses/GPU on {args.grid}x{args.grid} "
-                            "occupancy grid (border + Bernoulli 0.05), demo car",
+                            f"occupancy grid (border + Bernoulli 0.05), {args.car} car",
                 "poses_per_gpu": n, "grid": args.grid, "parallelism": f"pose-sharded x{E.world}"})
     wl.step = lambda: api.collision_flags_dev(E.ctx, omap, E.conf, dx, dy, dyaw, flags)
 
@@ -452,6 +456,8 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx = api.Context(dev_index, stream.cuda_stream)
     conf = A.demo_config()
+    if args.car == "compact":
+        conf.car.center2front, conf.car.center2back, conf.car.width, conf.extend_bound = 3.0, 1.0, 1.8, 0.2
     if args.band > 0:
         assert ctx.lib.pp_ctx_set_relax_band(ctx.h, args.band) == 0
     E = SimpleNamespace(torch=torch, api=api, W=W, A=A, S=S, ctx=ctx, conf=conf, dev=dev, rank=rank, world=world)

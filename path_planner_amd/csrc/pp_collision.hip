@@ -5,7 +5,8 @@
 // the bucketed point list (PpBuckets); see pp_device.h for the predicate.
 #include "pp_device.h"
 
-template <bool LATTICE>
+// ROWS: window rows of the lattice filter this instance is compiled for (8 or 16; unused without a lattice)
+template <bool LATTICE, int ROWS>
 __global__ void __launch_bounds__(128)
 k_collision(uint64_t n, const double* __restrict__ x, const double* __restrict__ y,
             const double* __restrict__ yaw, uint8_t* __restrict__ flags, PpFootprint f,
@@ -25,7 +26,7 @@ k_collision(uint64_t n, const double* __restrict__ x, const double* __restrict__
     }
     unsigned r;
     if (LATTICE) {
-      r = pp_pose_yaw_vs_lattice(px, py, pyaw, f, lat);
+      r = pp_pose_yaw_vs_lattice<ROWS>(px, py, pyaw, f, lat);
     } else {
       double s, c;
       sincos(pyaw, &s, &c);
@@ -45,11 +46,14 @@ static int32_t launch_collision(pp_ctx* ctx, const pp_map* map, const pp_config*
   const unsigned block = 128;
   const unsigned grid = (unsigned)std::max<uint64_t>(
       1, std::min<uint64_t>((n + block - 1) / block, (uint64_t)ctx->num_cus * 128));
-  if (map->lattice)
-    hipLaunchKernelGGL(k_collision<true>, dim3(grid), dim3(block), 0, ctx->stream, n, d_x, d_y,
+  if (map->lattice && f.scan_small)
+    hipLaunchKernelGGL((k_collision<true, 8>), dim3(grid), dim3(block), 0, ctx->stream, n, d_x, d_y,
+                       d_yaw, d_flags, f, map->lat, map->bk);
+  else if (map->lattice)
+    hipLaunchKernelGGL((k_collision<true, 16>), dim3(grid), dim3(block), 0, ctx->stream, n, d_x, d_y,
                        d_yaw, d_flags, f, map->lat, map->bk);
   else
-    hipLaunchKernelGGL(k_collision<false>, dim3(grid), dim3(block), 0, ctx->stream, n, d_x, d_y,
+    hipLaunchKernelGGL((k_collision<false, 16>), dim3(grid), dim3(block), 0, ctx->stream, n, d_x, d_y,
                        d_yaw, d_flags, f, map->lat, map->bk);
   PP_HIP(ctx, hipGetLastError());
   return PP_OK;

@@ -148,6 +148,10 @@ PpFootprint pp_make_footprint(const pp_config* conf) {
   f.scan_wi = std::nextafter((float)(f.bound_wid - inflate), -1e30f);
   f.scan_ok = (std::isfinite(f.bound_radius) && f.bound_radius + 2.0 * inflate <= 6.0 &&
                f.bound_len >= 0.0 && f.bound_wid >= 0.0) ? 1 : 0;
+  f.scan_small = (f.scan_ok && f.bound_radius + 2.0 * inflate <= 3.0) ? 1 : 0;
+#ifdef PP_LAB_NO_SCAN_SMALL
+  f.scan_small = 0;
+#endif
   return f;
 }
 

@@ -182,6 +182,13 @@ __device__ __forceinline__ bool pp_sincos_f32(double yaw, float& sf, float& cf) 
 }
 
 // Result of the filter: 0 = miss, 1 = hit, 2 = undecided.
+// ROWS = 16: the window described above.  ROWS = 8 (f.scan_small: bounding radius below 3 cells):
+// the footprint reaches rows floor(gy)-3 .. +3 only; the two block rows from the one that holds
+// floor(gy)-3 cover them unless that row is the third or fourth of its block row, and then a third
+// block row is fetched by the lanes still without a candidate.  (Two 16-byte loads that start at
+// the row itself would always do, but a 16-byte load that is only 4-byte aligned is handled one
+// dword at a time: measured slower than three aligned ones.)
+template <int ROWS>
 __device__ __forceinline__ int pp_lattice_filter(double x, double y, float cf, float sf,
                                                  const PpFootprint& f, const PpLattice& g) {
   // footprint centre from the fp32 direction: off by < 1e-6, inside the filter's margins
@@ -194,8 +201,10 @@ __device__ __forceinline__ int pp_lattice_filter(double x, double y, float cf, f
   const double bxf = floor(gx), byf = floor(gy);
   const int ibx = (int)bxf, iby = (int)byf;
   const float fx = (float)(gx - bxf), fy = (float)(gy - byf);
-  const int ix0 = ibx - 6, ytop = iby - 6, o = ytop & 3;  // window rows start at yb = ytop - o
-  const float wx = 6.0f + fx, wy = (float)(6 + o) + fy;  // centre in window coordinates
+  constexpr int kUp = ROWS == 8 ? 3 : 6;               // rows below the centre's row in the window
+  const int ix0 = ibx - 6, ytop = iby - kUp;
+  const int o = ytop & 3;                              // window rows start at yb = ytop - o
+  const float wx = 6.0f + fx, wy = (float)(kUp + o) + fy;  // centre in window coordinates
 
   const float acf = __builtin_fabsf(cf), asf = __builtin_fabsf(sf);
   const float exo = __builtin_fmaf(acf, f.scan_lo, asf * f.scan_wo);  // half-extent in x
@@ -223,17 +232,29 @@ __device__ __forceinline__ int pp_lattice_filter(double x, double y, float cf, f
 
   // the tile that starts at or before the window's low corner holds all of it: rows ytop & 15 ..
   // + 12 < 32, columns (ix0 & 15) .. + 12 < 32; the four block rows from yb are uint4 (yb & 15) >> 2 .. + 3
+  unsigned key = 0;
   const uint4* base = g.tiles + (((size_t)(ix0 >> 4) * (size_t)g.nty + (size_t)(ytop >> 4)) * 8 +
                                  (size_t)((ytop & 15) >> 2));
-  const uint4 l1 = base[1], l2 = base[2];
-  unsigned key = 0;
-  key = pp_scan_rows4<4>(q, l1, key);
-  key = pp_scan_rows4<8>(q, l2, key);
-  if (key < 16) {
-    const uint4 l0 = base[0], l3 = base[3];
+  if (ROWS == 8) {
+    const uint4 l0 = base[0], l1 = base[1];
     key = pp_scan_rows4<0>(q, l0, key);
-    key = pp_scan_rows4<12>(q, l3, key);
-    if (key < 16) return 0;
+    key = pp_scan_rows4<4>(q, l1, key);
+    if (key < 16) {
+      if (o < 2) return 0;  // rows o .. o + 6 end inside the second block row
+      const uint4 l2 = base[2];
+      key = pp_scan_rows4<8>(q, l2, key);
+      if (key < 16) return 0;
+    }
+  } else {
+    const uint4 l1 = base[1], l2 = base[2];
+    key = pp_scan_rows4<4>(q, l1, key);
+    key = pp_scan_rows4<8>(q, l2, key);
+    if (key < 16) {
+      const uint4 l0 = base[0], l3 = base[3];
+      key = pp_scan_rows4<0>(q, l0, key);
+      key = pp_scan_rows4<12>(q, l3, key);
+      if (key < 16) return 0;
+    }
   }
   // one candidate cell against the deflated rectangle
   const float dx = (float)__builtin_ctz(key >> 4) + (float)kLatticeShift - wxs, dy = (float)(key & 15u) - wy;
@@ -254,18 +275,22 @@ __device__ __forceinline__ unsigned pp_lattice_exact(double x, double y, double 
 __device__ __forceinline__ unsigned pp_pose_vs_lattice(double x, double y, double c, double s,
                                                        const PpFootprint& f, const PpLattice& g) {
   if (f.scan_ok) {
-    const int r = pp_lattice_filter(x, y, (float)c, (float)s, f, g);
+    const int r = f.scan_small ? pp_lattice_filter<8>(x, y, (float)c, (float)s, f, g)
+                               : pp_lattice_filter<16>(x, y, (float)c, (float)s, f, g);
     if (r < 2) return r ? PP_F_HIT : 0u;
   }
   return pp_lattice_exact(x, y, c, s, f, g);
 }
 
-// Pose given by its yaw: fp32 direction for the filter, fp64 sin/cos only when undecided.
+// Pose given by its yaw: fp32 direction for the filter, fp64 sin/cos only when undecided.  ROWS = 0
+// picks the window by the footprint at run time; 8 / 16 are for kernels compiled for one of them.
+template <int ROWS = 0>
 __device__ __forceinline__ unsigned pp_pose_yaw_vs_lattice(double x, double y, double yaw,
                                                            const PpFootprint& f, const PpLattice& g) {
   float sf, cf;
   if (f.scan_ok && pp_sincos_f32(yaw, sf, cf)) {
-    const int r = pp_lattice_filter(x, y, cf, sf, f, g);
+    const int r = (ROWS == 8 || (ROWS == 0 && f.scan_small)) ? pp_lattice_filter<8>(x, y, cf, sf, f, g)
+                                                             : pp_lattice_filter<16>(x, y, cf, sf, f, g);
     if (r < 2) return r ? PP_F_HIT : 0u;
   }
   double s, c;

@@ -27,6 +27,7 @@ struct PpFootprint {
   // (scan_lo, scan_wo) and of the deflated one (scan_li, scan_wi), rounded outward / inward
   float scan_lo, scan_wo, scan_li, scan_wi;
   int32_t scan_ok;
+  int32_t scan_small;  // bound_radius + inflation <= 3 cells: an eight-row window holds the footprint
 };
 
 // Occupancy of an integer-lattice obstacle set, bit-packed for gather locality.

@@ -71,6 +71,62 @@ def test_collision_random_grid_vs_oracle(ctx, size, p, n):
     assert (got2 == got).all()
 
 
+def small_car_config(front, back, width, extend):
+    c = A.demo_config()
+    c.car.center2front, c.car.center2back, c.car.width = front, back, width
+    c.extend_bound = extend
+    return c
+
+
+@pytest.mark.parametrize("front,back,width,extend", [
+    (3.0, 1.0, 1.8, 0.2),                    # a compact car: bounding radius 2.46 cells, eight-row window
+    (1.0, 1.0, 1.0, 0.0),                    # radius 1.12
+    (4.0, 1.0, 2.0, 0.2499),                 # radius 2.9995: just inside the eight-row window's limit
+    (4.0, 1.0, 2.0, 0.2509),                 # radius 3.0005: just outside, sixteen rows
+])
+def test_collision_small_footprints_vs_oracle(ctx, front, back, width, extend):
+    """Footprints whose bounding radius is below three cells take the filter's eight-row window;
+    flags must equal the oracle's on either side of that limit."""
+    conf = small_car_config(front, back, width, extend)
+    for size, p, n in ((256, 0.05, 150000), (192, 0.3, 50000)):
+        occ = W.occupancy_grid(size, p)
+        ox, oy = W.raster_to_points(occ)
+        x, y, yaw = W.random_poses(n, size)
+        x[:100] -= 30.0
+        y[100:200] += size
+        yaw[200:264] = np.repeat([0.0, math.pi / 2, -math.pi / 2, math.pi], 16)  # axis-aligned edges
+        m = api.ObstacleMap(ctx, raster=occ)
+        got = api.collision_flags(ctx, m, conf, x, y, yaw)
+        st, exp = O.OracleMap(ox, oy).collision_flags(conf, x, y, yaw)
+        assert st == 0
+        assert assert_flags_equal(got, exp) == 0
+        assert 0.01 < exp.mean() < 1.0
+
+
+def test_expand_small_footprint_vs_oracle(ctx):
+    """The rollout kernel's subsampled collision checks with the eight-row window."""
+    conf = small_car_config(3.0, 1.0, 1.8, 0.2)
+    occ = W.occupancy_grid(128, 0.03)
+    ox, oy = W.raster_to_points(occ)
+    m = api.ObstacleMap(ctx, raster=occ)
+    om = O.OracleMap(ox, oy)
+    rng = np.random.default_rng(21)
+    n = 400
+    px, py = rng.uniform(3, 124, n), rng.uniform(3, 124, n)
+    pyaw = rng.uniform(-math.pi, math.pi, n)
+    pdir = rng.choice([-1, 1], n)
+    steer, _ = api.calc_motion_set(conf)
+    psteer = rng.choice(steer, n)
+    pcost = rng.uniform(0, 100, n)
+    got = api.expand(ctx, m, conf, px, py, pyaw, pdir, psteer, pcost)
+    st, exp = om.expand(conf, px, py, pyaw, pdir, psteer, pcost)
+    assert st == 0
+    ok = (got["valid"] & 2) == 0
+    assert (~ok).sum() <= 2
+    assert ((got["valid"] & 1)[ok] == exp["valid"][ok]).all()
+    assert 0.05 < exp["valid"].mean() < 0.95
+
+
 def test_collision_bucket_path_vs_oracle(ctx):
     rng = np.random.default_rng(5)
     ox, oy = rng.uniform(-20, 80, 3000), rng.uniform(-20, 80, 3000)

@@ -41,6 +41,9 @@ struct PpExpandDev {
   const double* hblk = nullptr;
   uint32_t hblk_nty = 0;
   uint64_t hblk_plane_cols = 0;
+  // optional: entries of primitives that are not valid keep whatever the arrays held (only the
+  // valid byte is written) -- for outputs that cross PCIe
+  int32_t sparse = 0;
 };
 
 struct PpExpandPlan {

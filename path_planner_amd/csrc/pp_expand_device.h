@@ -112,9 +112,10 @@ __device__ __forceinline__ void pp_expand_item(uint64_t t, uint32_t n_prim, cons
         fc = __longlong_as_double(0x7FF8000000000000ll);
       }
     }
-    out.fcost[t] = fc;
+    if (!(out.sparse && !valid)) out.fcost[t] = fc;
   }
   out.valid[t] = (uint8_t)v;
+  if (out.sparse && !valid) return;  // the caller reads the other arrays only where bit 0 is set
   out.xind[t] = valid ? xind : 0;
   out.yind[t] = valid ? yind : 0;
   out.yawind[t] = valid ? yawind : 0;

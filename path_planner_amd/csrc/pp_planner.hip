@@ -69,6 +69,14 @@ class KeyMap {
     }
   }
   bool contains(uint64_t key) { return find(key) != nullptr; }
+  // Asks for the cache lines a lookup of `key` starts at (a batch of thousands of queries finds
+  // none of its tables in cache when its turn comes).
+  void prefetch(uint64_t key) const {
+    if (cap_ == 0) return;
+    const size_t i = hash(key) & (cap_ - 1);
+    __builtin_prefetch(&val_[i]);
+    __builtin_prefetch(&key_[i]);
+  }
   void set(uint64_t key, int32_t v) {  // insert or overwrite
     if (int32_t* p = find(key)) {
       *p = v;
@@ -537,6 +545,10 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   constexpr size_t kSpecItems = PP_SPEC_ITEMS, kSpecDepth = PP_SPEC_DEPTH, kCacheMax = 256;
   constexpr size_t kRoundFusedMax = 1024;  // nodes; below this a round is one launch
   constexpr size_t kRoundDirectMax = 128;  // nodes; below this the kernels work on the pinned staging area
+#ifndef PP_ROUND_OUT_HOST_MIN
+#define PP_ROUND_OUT_HOST_MIN 128
+#endif
+  constexpr size_t kRoundOutHostMin = PP_ROUND_OUT_HOST_MIN;  // nodes; from this on results go straight to it
   const size_t B = std::max<size_t>(nq, kSpecItems + kSpecDepth);
   const size_t items = B * NP;
   size_t off = 0;
@@ -601,6 +613,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   Pool& pool = workers ? *state.pool : serial;
   std::vector<uint32_t> live_ids;
   live_ids.reserve(nq);
+  std::vector<uint8_t> alive;
 
   // ---- lock-step rounds
   const double* mot = plan.motion.data();
@@ -628,6 +641,16 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       q.live = false;
       return;
     }
+    // keys of the valid children first, with their table lines requested, then the lookups
+    uint64_t ckey[256];
+    const bool keyed = NP <= 256;
+    if (keyed)
+      for (uint32_t i = 0; i < NP; ++i)
+        if (v.valid[i] & 1u) {
+          ckey[i] = calc_index(v.xind[i], v.yind[i], v.yawind[i], P);
+          q.closed.prefetch(ckey[i]);
+          q.open.prefetch(ckey[i]);
+        }
     for (uint32_t i = 0; i < NP; ++i) {
       ++q.st.rollouts;
       const uint8_t vf = v.valid[i];
@@ -639,7 +662,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         return;
       }
       if (!(vf & 1u)) continue;
-      const uint64_t key = calc_index(v.xind[i], v.yind[i], v.yawind[i], P);
+      const uint64_t key = keyed ? ckey[i] : calc_index(v.xind[i], v.yind[i], v.yawind[i], P);
       if (q.closed.contains(key)) continue;
       const double cost = v.cost[i];
       int32_t* it = q.open.find(key);
@@ -756,23 +779,33 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     // (1) every live query closes nodes until one needs the device
     const double p0 = prof ? now_ms() : 0.0;
     pc = live_ids.size() < 64 ? 1 : 0;
-    pool.run(live_ids.size(), [&](size_t k) { advance(Q[live_ids[k]]); });
+    // the workers leave each query's state in a flat array: the loops below that run on this
+    // thread alone must not touch thousands of query objects (a cache miss apiece)
+    alive.resize(live_ids.size());
+    pool.run(live_ids.size(), [&](size_t k) {
+      Query& q = Q[live_ids[k]];
+      advance(q);
+      alive[k] = q.live;
+      q.want.clear();
+      q.want.push_back(q.curr);
+    });
     if (prof) p_adv[pc] += now_ms() - p0;
     const double p1 = prof ? now_ms() : 0.0;
     size_t nl = 0;
-    for (uint32_t id : live_ids)
-      if (Q[id].live) live_ids[nl++] = id;
+    for (size_t k = 0; k < live_ids.size(); ++k)
+      if (alive[k]) live_ids[nl++] = live_ids[k];
     live_ids.resize(nl);
     if (nl == 0) break;
     const size_t depth = std::min<size_t>(kSpecDepth, std::max<size_t>(1, kSpecItems / nl));
-    size_t ni = 0;
-    for (uint32_t id : live_ids) {
-      Query& q = Q[id];
-      q.want.clear();
-      q.want.push_back(q.curr);
-      if (depth > 1) speculate(q, depth);
-      q.item0 = ni;
-      ni += q.want.size();
+    size_t ni = nl;  // one node per query (item = position in the live list) ...
+    if (depth > 1) {  // ... unless few queries are left and each also sends nodes it may close soon
+      ni = 0;
+      for (uint32_t id : live_ids) {
+        Query& q = Q[id];
+        speculate(q, depth);
+        q.item0 = ni;
+        ni += q.want.size();
+      }
     }
 
     // (2) stage the nodes, launch, fetch.  Inputs and outputs are laid out for this round's number
@@ -797,7 +830,8 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     double* hcost = (double*)(h + r_cost);
     int32_t* hhid = (int32_t*)(h + r_hid);
     pool.run(nl, [&](size_t li) {  // every query fills its own slots
-      const Query& q = Q[live_ids[li]];
+      Query& q = Q[live_ids[li]];
+      if (depth == 1) q.item0 = li;
       for (size_t j = 0; j < q.want.size(); ++j) {
         const SNode& n = q.nodes[q.want[j]];
         const size_t k = q.item0 + j;
@@ -827,30 +861,36 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     const bool direct = ni < kRoundDirectMax;
     char* const d = direct ? h : dw;
     if (!direct) PP_HIP(ctx, hipMemcpyAsync(d, h, r_in, hipMemcpyHostToDevice, s));
-    eo.valid = (uint8_t*)(d + r_valid);
-    eo.xind = (uint64_t*)(d + r_xind);
-    eo.yind = (uint64_t*)(d + r_yind);
-    eo.yawind = (int64_t*)(d + r_yaw);
-    eo.cost = (double*)(d + r_c);
-    eo.end_x = (double*)(d + r_ex);
-    eo.end_y = (double*)(d + r_ey);
-    eo.end_yaw = (double*)(d + r_eyaw);
-    eo.fcost = (double*)(d + r_f);
+    // A large round writes its results straight into the pinned area as well: full-wave stores
+    // cross PCIe while the kernels run, where a copy afterwards takes as long again as the kernels
+    // (the inputs stay in device memory: they are read once per primitive).
+    const bool out_host = !direct && ni >= kRoundOutHostMin;
+    char* const od = out_host ? h : d;
+    eo.sparse = out_host ? 1 : 0;
+    eo.valid = (uint8_t*)(od + r_valid);
+    eo.xind = (uint64_t*)(od + r_xind);
+    eo.yind = (uint64_t*)(od + r_yind);
+    eo.yawind = (int64_t*)(od + r_yaw);
+    eo.cost = (double*)(od + r_c);
+    eo.end_x = (double*)(od + r_ex);
+    eo.end_y = (double*)(od + r_ey);
+    eo.end_yaw = (double*)(od + r_eyaw);
+    eo.fcost = (double*)(od + r_f);
     eo.hmap_id = (const int32_t*)(d + r_hid);
     const double* dq = (const double*)(d + r_q);
     if (ni < kRoundFusedMax) {
-      pp_round_launch(ctx, map, conf, plan, (uint32_t)ni, dq, maxc, (PpShotOut*)(d + r_shot),
+      pp_round_launch(ctx, map, conf, plan, (uint32_t)ni, dq, maxc, (PpShotOut*)(od + r_shot),
                       (const int64_t*)(d + r_dir), (const double*)(d + r_steer), (const double*)(d + r_cost),
                       (const double*)d_mot, eo);
     } else {
       pp_rs_words_launch(ctx, ni, dq, maxc, (PpRsCand*)(dw + o_cand), (PpRsPair*)(dw + o_pair));
       pp_rs_shot_launch(ctx, map, conf, (uint32_t)ni, dq, maxc, (const PpRsCand*)(dw + o_cand),
-                        (const PpRsPair*)(dw + o_pair), (PpShotOut*)(d + r_shot));
+                        (const PpRsPair*)(dw + o_pair), (PpShotOut*)(od + r_shot));
       pp_expand_launch(ctx, map, plan, ni, dq, dq + ni, dq + 2 * ni, (const int64_t*)(d + r_dir),
                        (const double*)(d + r_steer), (const double*)(d + r_cost), (const double*)d_mot, eo);
     }
     PP_HIP(ctx, hipGetLastError());
-    if (!direct) PP_HIP(ctx, hipMemcpyAsync(h + r_in, d + r_in, r_out, hipMemcpyDeviceToHost, s));
+    if (!direct && !out_host) PP_HIP(ctx, hipMemcpyAsync(h + r_in, d + r_in, r_out, hipMemcpyDeviceToHost, s));
     PP_HIP(ctx, hipStreamSynchronize(s));
     const double p3 = prof ? now_ms() : 0.0;
     if (prof) p_dev[pc] += p3 - p2;

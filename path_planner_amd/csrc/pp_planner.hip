@@ -613,7 +613,15 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   Pool& pool = workers ? *state.pool : serial;
   std::vector<uint32_t> live_ids;
   live_ids.reserve(nq);
-  std::vector<uint8_t> alive;
+  // what the device needs of the node a query wants expanded (one record per live query)
+  struct Emit {
+    double x, y, yaw, gx, gy, gyaw;
+    int64_t dir;
+    double steer, cost;
+    int32_t hid;
+    uint8_t alive;
+  };
+  std::vector<Emit> emit;
 
   // ---- lock-step rounds
   const double* mot = plan.motion.data();
@@ -775,27 +783,49 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   double p_adv[2] = {0, 0}, p_stage[2] = {0, 0}, p_dev[2] = {0, 0}, p_apply[2] = {0, 0};
   uint64_t p_rounds[2] = {0, 0}, p_items[2] = {0, 0}, p_live[2] = {0, 0};
   int pc = 0;
-  for (;;) {
-    // (1) every live query closes nodes until one needs the device
+  // (1) A query closes nodes until one needs the device, and leaves what the device needs of that
+  // node in a flat record: the loops of a round that run on this thread alone, and the staging
+  // of a large round, then never touch the query objects (thousands of them, a cache miss apiece).
+  // After the first round this runs right behind the query's apply step, while its tables are
+  // still in cache.
+  emit.resize(live_ids.size());
+  auto advance_emit = [&](size_t k) {
+    Query& q = Q[live_ids[k]];
+    advance(q);
+    q.want.clear();
+    q.want.push_back(q.curr);
+    Emit& e = emit[k];
+    e.alive = q.live;
+    if (!q.live) return;
+    const SNode& n = q.nodes[q.curr];
+    e.x = n.x;
+    e.y = n.y;
+    e.yaw = n.yaw;
+    e.gx = q.goal[0];
+    e.gy = q.goal[1];
+    e.gyaw = q.goal[2];
+    e.dir = n.direction;
+    e.steer = n.steer;
+    e.cost = n.cost;
+    e.hid = q.hmap_slot;
+  };
+  {
     const double p0 = prof ? now_ms() : 0.0;
-    pc = live_ids.size() < 64 ? 1 : 0;
-    // the workers leave each query's state in a flat array: the loops below that run on this
-    // thread alone must not touch thousands of query objects (a cache miss apiece)
-    alive.resize(live_ids.size());
-    pool.run(live_ids.size(), [&](size_t k) {
-      Query& q = Q[live_ids[k]];
-      advance(q);
-      alive[k] = q.live;
-      q.want.clear();
-      q.want.push_back(q.curr);
-    });
-    if (prof) p_adv[pc] += now_ms() - p0;
+    pool.run(live_ids.size(), advance_emit);
+    if (prof) p_adv[live_ids.size() < 64 ? 1 : 0] += now_ms() - p0;
+  }
+  for (;;) {
     const double p1 = prof ? now_ms() : 0.0;
     size_t nl = 0;
     for (size_t k = 0; k < live_ids.size(); ++k)
-      if (alive[k]) live_ids[nl++] = live_ids[k];
+      if (emit[k].alive) {
+        live_ids[nl] = live_ids[k];
+        emit[nl] = emit[k];
+        ++nl;
+      }
     live_ids.resize(nl);
     if (nl == 0) break;
+    pc = nl < 64 ? 1 : 0;
     const size_t depth = std::min<size_t>(kSpecDepth, std::max<size_t>(1, kSpecItems / nl));
     size_t ni = nl;  // one node per query (item = position in the live list) ...
     if (depth > 1) {  // ... unless few queries are left and each also sends nodes it may close soon
@@ -829,9 +859,22 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     double* hsteer = (double*)(h + r_steer);
     double* hcost = (double*)(h + r_cost);
     int32_t* hhid = (int32_t*)(h + r_hid);
-    pool.run(nl, [&](size_t li) {  // every query fills its own slots
+    if (depth == 1) {
+      pool.run(nl, [&](size_t k) {  // item = position in the live list, straight from the records
+        const Emit& e = emit[k];
+        hq[0 * ni + k] = e.x;
+        hq[1 * ni + k] = e.y;
+        hq[2 * ni + k] = e.yaw;
+        hq[3 * ni + k] = e.gx;
+        hq[4 * ni + k] = e.gy;
+        hq[5 * ni + k] = e.gyaw;
+        hdir[k] = e.dir;
+        hsteer[k] = e.steer;
+        hcost[k] = e.cost;
+        hhid[k] = e.hid;
+      });
+    } else pool.run(nl, [&](size_t li) {  // every query fills its own slots
       Query& q = Q[live_ids[li]];
-      if (depth == 1) q.item0 = li;
       for (size_t j = 0; j < q.want.size(); ++j) {
         const SNode& n = q.nodes[q.want[j]];
         const size_t k = q.item0 + j;
@@ -902,27 +945,29 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     const char* v_arr[8] = {h + r_xind, h + r_yind, h + r_yaw, h + r_c, h + r_ex, h + r_ey, h + r_eyaw, h + r_f};
     pool.run(nl, [&](size_t k) {
       Query& q = Q[live_ids[k]];
+      const size_t first = depth == 1 ? k : q.item0;
       // entries of nodes that were replaced in the open list are never asked for again: a long
       // search drops the lot now and then (whatever is still wanted is simply fetched again)
       if (q.cache.size() > kCacheMax) q.cache.clear();
       for (size_t j = 1; j < q.want.size(); ++j) {
-        const size_t it = q.item0 + j;
+        const size_t it = first + j;
         Expansion& e = q.cache[q.want[j]];
         e.shot = shot[it];
         e.valid.assign(v_valid + it * NP, v_valid + (it + 1) * NP);
         e.words.resize(8 * (size_t)NP);
         for (int a = 0; a < 8; ++a) std::memcpy(e.words.data() + (size_t)a * NP, v_arr[a] + it * NP * 8, (size_t)NP * 8);
       }
-      const size_t it = q.item0, b = it * NP;
+      const size_t it = first, b = it * NP;
       const ExpansionView v{&shot[it], v_valid + b, (const uint64_t*)v_arr[0] + b, (const uint64_t*)v_arr[1] + b,
                             (const int64_t*)v_arr[2] + b, (const double*)v_arr[3] + b, (const double*)v_arr[4] + b,
                             (const double*)v_arr[5] + b, (const double*)v_arr[6] + b, (const double*)v_arr[7] + b};
       if (beyond_limit(v)) {
-        need_grids.store(true, std::memory_order_relaxed);
-        return;  // q.curr stays: the node goes to the device again
+        need_grids.store(true, std::memory_order_relaxed);  // q.curr stays: the node goes to the device again
+      } else {
+        apply(q, v);
+        q.curr = -1;
       }
-      apply(q, v);
-      q.curr = -1;
+      advance_emit(k);  // the next node to expand, while the query's tables are in cache
     });
     if (need_grids.load(std::memory_order_relaxed)) {
       st = pp_wavefront_multi_finish(ctx);

@@ -299,6 +299,11 @@ class Pool {
 struct PlanState {
   std::vector<Query> queries;
   std::unique_ptr<Pool> pool;
+  hipEvent_t lane_done[2] = {nullptr, nullptr};  // a lane's results have reached the pinned area
+  ~PlanState() {
+    for (hipEvent_t e : lane_done)
+      if (e) (void)hipEventDestroy(e);
+  }
 };
 
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -549,8 +554,12 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
 #define PP_ROUND_OUT_HOST_MIN 128
 #endif
   constexpr size_t kRoundOutHostMin = PP_ROUND_OUT_HOST_MIN;  // nodes; from this on results go straight to it
-  const size_t B = std::max<size_t>(nq, kSpecItems + kSpecDepth);
-  const size_t items = B * NP;
+  // a large batch runs as two lanes (below), each with its own half of the staging buffers
+  constexpr size_t kTwoLanesMin = 1024, kLaneMergeBelow = 256;
+  const bool two_lanes = nq >= kTwoLanesMin;
+  const size_t Bl = two_lanes ? (nq + 1) / 2 : std::max<size_t>(nq, kSpecItems + kSpecDepth);  // items per lane
+  const size_t B = two_lanes ? 2 * Bl : Bl;
+  const size_t items = Bl * NP;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -560,8 +569,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   // per-round inputs (start pose + goal pose, pdir, psteer, pcost, hmap_id) and outputs share one
   // device buffer and one pinned mirror, laid out per round; the motion table and the
   // Reeds-Shepp work arrays sit behind them
-  const size_t io_bytes = al256(6 * B * 8) + 3 * al256(B * 8) + al256(B * 4) + al256(B * sizeof(PpShotOut)) +
-                          al256(items) + 8 * al256(items * 8);
+  const size_t io_lane = al256(6 * Bl * 8) + 3 * al256(Bl * 8) + al256(Bl * 4) + al256(Bl * sizeof(PpShotOut)) +
+                         al256(items) + 8 * al256(items * 8);
+  const size_t io_bytes = (two_lanes ? 2 : 1) * io_lane;
   off = io_bytes;
   const size_t o_mot = take(plan.motion.size() * 8);
   const size_t o_cand = take(B * PP_RS_MAX_PATHS * sizeof(PpRsCand)), o_pair = take(B * sizeof(PpRsPair));
@@ -597,8 +607,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   // set by any query whose expansion met a heuristic value beyond the limit: that expansion is
   // not applied, the grids are completed after the round and the node is expanded again
   std::atomic<bool> need_grids{false};
-  auto beyond_limit = [&](const ExpansionView& v) {
-    if (!h_bounded) return false;
+  auto beyond_limit = [&](const ExpansionView& v) {  // the mark is only ever set by a launch on bounded grids
     for (uint32_t i = 0; i < NP; ++i)
       if ((v.valid[i] & 17u) == 17u) return true;
     return false;
@@ -611,8 +620,8 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   Pool serial(0);
   if (workers && !state.pool) state.pool.reset(new Pool(workers));
   Pool& pool = workers ? *state.pool : serial;
-  std::vector<uint32_t> live_ids;
-  live_ids.reserve(nq);
+  for (hipEvent_t& e : state.lane_done)
+    if (!e) PP_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   // what the device needs of the node a query wants expanded (one record per live query)
   struct Emit {
     double x, y, yaw, gx, gy, gyaw;
@@ -621,7 +630,6 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     int32_t hid;
     uint8_t alive;
   };
-  std::vector<Emit> emit;
 
   // ---- lock-step rounds
   const double* mot = plan.motion.data();
@@ -777,24 +785,46 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     for (size_t k = 0; k < nc && q.want.size() < depth; ++k) q.want.push_back(cand[k].id);
   };
 
-  for (uint64_t i = 0; i < nq; ++i)
-    if (Q[i].live) live_ids.push_back((uint32_t)i);
   const bool prof = getenv("PP_PLAN_PROFILE") != nullptr;
   double p_adv[2] = {0, 0}, p_stage[2] = {0, 0}, p_dev[2] = {0, 0}, p_apply[2] = {0, 0};
   uint64_t p_rounds[2] = {0, 0}, p_items[2] = {0, 0}, p_live[2] = {0, 0};
-  int pc = 0;
+
+  // A lane is a set of queries that go through their rounds together.  A large batch runs as two
+  // lanes that take turns: while the device works on one lane's nodes, the host applies the other
+  // lane's results, pops its next nodes and stages them.  Both use the one stream, so a lane's
+  // launches queue up behind the other lane's and its event says when its own results are in.
+  struct Lane {
+    std::vector<uint32_t> ids;  // live queries
+    std::vector<Emit> emit;     // ids[k]'s next node
+    size_t io_base = 0;         // the lane's part of the staging buffers (pinned and device), bytes
+    size_t item_base = 0;       // the lane's part of the Reeds-Shepp work arrays, items
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+    int pc = 0;
+    size_t nl = 0, ni = 0, depth = 1;
+    size_t r_shot = 0, r_valid = 0, r_arr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  };
+  const size_t nlanes = two_lanes ? 2 : 1;
+  Lane lanes[2];
+  for (size_t l = 0; l < nlanes; ++l) {
+    lanes[l].io_base = l * io_lane;
+    lanes[l].item_base = l * Bl;
+    lanes[l].done = state.lane_done[l];
+  }
+  for (uint64_t i = 0, k = 0; i < nq; ++i)
+    if (Q[i].live) lanes[k++ % nlanes].ids.push_back((uint32_t)i);
+
   // (1) A query closes nodes until one needs the device, and leaves what the device needs of that
   // node in a flat record: the loops of a round that run on this thread alone, and the staging
   // of a large round, then never touch the query objects (thousands of them, a cache miss apiece).
   // After the first round this runs right behind the query's apply step, while its tables are
   // still in cache.
-  emit.resize(live_ids.size());
-  auto advance_emit = [&](size_t k) {
-    Query& q = Q[live_ids[k]];
+  auto advance_emit = [&](Lane& ln, size_t k) {
+    Query& q = Q[ln.ids[k]];
     advance(q);
     q.want.clear();
     q.want.push_back(q.curr);
-    Emit& e = emit[k];
+    Emit& e = ln.emit[k];
     e.alive = q.live;
     if (!q.live) return;
     const SNode& n = q.nodes[q.curr];
@@ -809,38 +839,37 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     e.cost = n.cost;
     e.hid = q.hmap_slot;
   };
-  {
-    const double p0 = prof ? now_ms() : 0.0;
-    pool.run(live_ids.size(), advance_emit);
-    if (prof) p_adv[live_ids.size() < 64 ? 1 : 0] += now_ms() - p0;
-  }
-  for (;;) {
+
+  // (2) stage the lane's nodes and launch.  Inputs and outputs are laid out for this round's
+  // number of items, so each direction is one copy of exactly what is used.
+  auto launch = [&](Lane& ln) -> int32_t {
     const double p1 = prof ? now_ms() : 0.0;
     size_t nl = 0;
-    for (size_t k = 0; k < live_ids.size(); ++k)
-      if (emit[k].alive) {
-        live_ids[nl] = live_ids[k];
-        emit[nl] = emit[k];
+    for (size_t k = 0; k < ln.ids.size(); ++k)
+      if (ln.emit[k].alive) {
+        ln.ids[nl] = ln.ids[k];
+        ln.emit[nl] = ln.emit[k];
         ++nl;
       }
-    live_ids.resize(nl);
-    if (nl == 0) break;
-    pc = nl < 64 ? 1 : 0;
+    ln.ids.resize(nl);
+    ln.emit.resize(nl);
+    ln.nl = nl;
+    if (nl == 0) return PP_OK;
+    ln.pc = nl < 64 ? 1 : 0;
     const size_t depth = std::min<size_t>(kSpecDepth, std::max<size_t>(1, kSpecItems / nl));
     size_t ni = nl;  // one node per query (item = position in the live list) ...
     if (depth > 1) {  // ... unless few queries are left and each also sends nodes it may close soon
       ni = 0;
-      for (uint32_t id : live_ids) {
+      for (uint32_t id : ln.ids) {
         Query& q = Q[id];
         speculate(q, depth);
         q.item0 = ni;
         ni += q.want.size();
       }
     }
-
-    // (2) stage the nodes, launch, fetch.  Inputs and outputs are laid out for this round's number
-    // of items, so each direction is one copy of exactly what is used.
-    size_t ro = 0;
+    ln.depth = depth;
+    ln.ni = ni;
+    size_t ro = ln.io_base;
     auto rtake = [&](size_t bytes) {
       size_t o = ro;
       ro += al256(bytes);
@@ -850,9 +879,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     const size_t r_hid = rtake(ni * 4);
     const size_t r_in = ro;
     const size_t itn = ni * NP;
-    const size_t r_shot = rtake(ni * sizeof(PpShotOut)), r_valid = rtake(itn);
-    const size_t r_xind = rtake(itn * 8), r_yind = rtake(itn * 8), r_yaw = rtake(itn * 8), r_c = rtake(itn * 8);
-    const size_t r_ex = rtake(itn * 8), r_ey = rtake(itn * 8), r_eyaw = rtake(itn * 8), r_f = rtake(itn * 8);
+    ln.r_shot = rtake(ni * sizeof(PpShotOut));
+    ln.r_valid = rtake(itn);
+    for (int a = 0; a < 8; ++a) ln.r_arr[a] = rtake(itn * 8);  // xind, yind, yawind, cost, end x, end y, end yaw, f
     const size_t r_out = ro - r_in;
     double* hq = (double*)(h + r_q);
     int64_t* hdir = (int64_t*)(h + r_dir);
@@ -861,7 +890,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     int32_t* hhid = (int32_t*)(h + r_hid);
     if (depth == 1) {
       pool.run(nl, [&](size_t k) {  // item = position in the live list, straight from the records
-        const Emit& e = emit[k];
+        const Emit& e = ln.emit[k];
         hq[0 * ni + k] = e.x;
         hq[1 * ni + k] = e.y;
         hq[2 * ni + k] = e.yaw;
@@ -873,78 +902,92 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         hcost[k] = e.cost;
         hhid[k] = e.hid;
       });
-    } else pool.run(nl, [&](size_t li) {  // every query fills its own slots
-      Query& q = Q[live_ids[li]];
-      for (size_t j = 0; j < q.want.size(); ++j) {
-        const SNode& n = q.nodes[q.want[j]];
-        const size_t k = q.item0 + j;
-        hq[0 * ni + k] = n.x;
-        hq[1 * ni + k] = n.y;
-        hq[2 * ni + k] = n.yaw;
-        hq[3 * ni + k] = q.goal[0];
-        hq[4 * ni + k] = q.goal[1];
-        hq[5 * ni + k] = q.goal[2];
-        hdir[k] = n.direction;
-        hsteer[k] = n.steer;
-        hcost[k] = n.cost;
-        hhid[k] = q.hmap_slot;
-      }
-    });
+    } else {
+      pool.run(nl, [&](size_t li) {  // every query fills its own slots
+        Query& q = Q[ln.ids[li]];
+        for (size_t j = 0; j < q.want.size(); ++j) {
+          const SNode& n = q.nodes[q.want[j]];
+          const size_t k = q.item0 + j;
+          hq[0 * ni + k] = n.x;
+          hq[1 * ni + k] = n.y;
+          hq[2 * ni + k] = n.yaw;
+          hq[3 * ni + k] = q.goal[0];
+          hq[4 * ni + k] = q.goal[1];
+          hq[5 * ni + k] = q.goal[2];
+          hdir[k] = n.direction;
+          hsteer[k] = n.steer;
+          hcost[k] = n.cost;
+          hhid[k] = q.hmap_slot;
+        }
+      });
+    }
     const double p2 = prof ? now_ms() : 0.0;
     if (prof) {
-      p_stage[pc] += p2 - p1;
-      ++p_rounds[pc];
-      p_items[pc] += ni;
-      p_live[pc] += nl;
+      p_stage[ln.pc] += p2 - p1;
+      ++p_rounds[ln.pc];
+      p_items[ln.pc] += ni;
+      p_live[ln.pc] += nl;
     }
     // A round of few nodes skips both staging copies (each a blit kernel of its own, with its
     // launch gap): the kernels read and write the pinned area itself.  Only for few nodes -- every
     // primitive reads its parent's pose, and over PCIe that does not scale.
     char* const dw = d;  // the Reeds-Shepp work arrays stay in device memory
     const bool direct = ni < kRoundDirectMax;
-    char* const d = direct ? h : dw;
-    if (!direct) PP_HIP(ctx, hipMemcpyAsync(d, h, r_in, hipMemcpyHostToDevice, s));
+    char* const dd = direct ? h : dw;
+    if (!direct) PP_HIP(ctx, hipMemcpyAsync(dd + ln.io_base, h + ln.io_base, r_in - ln.io_base, hipMemcpyHostToDevice, s));
     // A large round writes its results straight into the pinned area as well: full-wave stores
     // cross PCIe while the kernels run, where a copy afterwards takes as long again as the kernels
     // (the inputs stay in device memory: they are read once per primitive).
     const bool out_host = !direct && ni >= kRoundOutHostMin;
-    char* const od = out_host ? h : d;
+    char* const od = out_host ? h : dd;
     eo.sparse = out_host ? 1 : 0;
-    eo.valid = (uint8_t*)(od + r_valid);
-    eo.xind = (uint64_t*)(od + r_xind);
-    eo.yind = (uint64_t*)(od + r_yind);
-    eo.yawind = (int64_t*)(od + r_yaw);
-    eo.cost = (double*)(od + r_c);
-    eo.end_x = (double*)(od + r_ex);
-    eo.end_y = (double*)(od + r_ey);
-    eo.end_yaw = (double*)(od + r_eyaw);
-    eo.fcost = (double*)(od + r_f);
-    eo.hmap_id = (const int32_t*)(d + r_hid);
-    const double* dq = (const double*)(d + r_q);
+    eo.valid = (uint8_t*)(od + ln.r_valid);
+    eo.xind = (uint64_t*)(od + ln.r_arr[0]);
+    eo.yind = (uint64_t*)(od + ln.r_arr[1]);
+    eo.yawind = (int64_t*)(od + ln.r_arr[2]);
+    eo.cost = (double*)(od + ln.r_arr[3]);
+    eo.end_x = (double*)(od + ln.r_arr[4]);
+    eo.end_y = (double*)(od + ln.r_arr[5]);
+    eo.end_yaw = (double*)(od + ln.r_arr[6]);
+    eo.fcost = (double*)(od + ln.r_arr[7]);
+    eo.hmap_id = (const int32_t*)(dd + r_hid);
+    const double* dq = (const double*)(dd + r_q);
     if (ni < kRoundFusedMax) {
-      pp_round_launch(ctx, map, conf, plan, (uint32_t)ni, dq, maxc, (PpShotOut*)(od + r_shot),
-                      (const int64_t*)(d + r_dir), (const double*)(d + r_steer), (const double*)(d + r_cost),
+      pp_round_launch(ctx, map, conf, plan, (uint32_t)ni, dq, maxc, (PpShotOut*)(od + ln.r_shot),
+                      (const int64_t*)(dd + r_dir), (const double*)(dd + r_steer), (const double*)(dd + r_cost),
                       (const double*)d_mot, eo);
     } else {
-      pp_rs_words_launch(ctx, ni, dq, maxc, (PpRsCand*)(dw + o_cand), (PpRsPair*)(dw + o_pair));
-      pp_rs_shot_launch(ctx, map, conf, (uint32_t)ni, dq, maxc, (const PpRsCand*)(dw + o_cand),
-                        (const PpRsPair*)(dw + o_pair), (PpShotOut*)(od + r_shot));
-      pp_expand_launch(ctx, map, plan, ni, dq, dq + ni, dq + 2 * ni, (const int64_t*)(d + r_dir),
-                       (const double*)(d + r_steer), (const double*)(d + r_cost), (const double*)d_mot, eo);
+      PpRsCand* cands = (PpRsCand*)(dw + o_cand) + ln.item_base * PP_RS_MAX_PATHS;
+      PpRsPair* pairs = (PpRsPair*)(dw + o_pair) + ln.item_base;
+      pp_rs_words_launch(ctx, ni, dq, maxc, cands, pairs);
+      pp_rs_shot_launch(ctx, map, conf, (uint32_t)ni, dq, maxc, cands, pairs, (PpShotOut*)(od + ln.r_shot));
+      pp_expand_launch(ctx, map, plan, ni, dq, dq + ni, dq + 2 * ni, (const int64_t*)(dd + r_dir),
+                       (const double*)(dd + r_steer), (const double*)(dd + r_cost), (const double*)d_mot, eo);
     }
     PP_HIP(ctx, hipGetLastError());
-    if (!direct && !out_host) PP_HIP(ctx, hipMemcpyAsync(h + r_in, d + r_in, r_out, hipMemcpyDeviceToHost, s));
-    PP_HIP(ctx, hipStreamSynchronize(s));
-    const double p3 = prof ? now_ms() : 0.0;
-    if (prof) p_dev[pc] += p3 - p2;
+    if (!direct && !out_host) PP_HIP(ctx, hipMemcpyAsync(h + r_in, dd + r_in, r_out, hipMemcpyDeviceToHost, s));
+    PP_HIP(ctx, hipEventRecord(ln.done, s));
+    ln.in_flight = true;
+    if (prof) p_dev[ln.pc] += now_ms() - p2;
+    return PP_OK;
+  };
 
-    // (3) the closed node is applied straight from the staging buffer; the nodes fetched ahead of
-    // their turn go into the query's cache
-    const PpShotOut* shot = (const PpShotOut*)(h + r_shot);
-    const uint8_t* v_valid = (const uint8_t*)(h + r_valid);
-    const char* v_arr[8] = {h + r_xind, h + r_yind, h + r_yaw, h + r_c, h + r_ex, h + r_ey, h + r_eyaw, h + r_f};
-    pool.run(nl, [&](size_t k) {
-      Query& q = Q[live_ids[k]];
+  // (3) wait for the lane's results; the closed node is applied straight from the staging buffer,
+  // the nodes fetched ahead of their turn go into the query's cache
+  auto collect = [&](Lane& ln) -> int32_t {
+    if (!ln.in_flight) return PP_OK;
+    const double p2 = prof ? now_ms() : 0.0;
+    PP_HIP(ctx, hipEventSynchronize(ln.done));
+    ln.in_flight = false;
+    const double p3 = prof ? now_ms() : 0.0;
+    if (prof) p_dev[ln.pc] += p3 - p2;
+    const PpShotOut* shot = (const PpShotOut*)(h + ln.r_shot);
+    const uint8_t* v_valid = (const uint8_t*)(h + ln.r_valid);
+    const char* v_arr[8];
+    for (int a = 0; a < 8; ++a) v_arr[a] = h + ln.r_arr[a];
+    const size_t depth = ln.depth;
+    pool.run(ln.nl, [&](size_t k) {
+      Query& q = Q[ln.ids[k]];
       const size_t first = depth == 1 ? k : q.item0;
       // entries of nodes that were replaced in the open list are never asked for again: a long
       // search drops the lot now and then (whatever is still wanted is simply fetched again)
@@ -967,17 +1010,61 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         apply(q, v);
         q.curr = -1;
       }
-      advance_emit(k);  // the next node to expand, while the query's tables are in cache
+      advance_emit(ln, k);  // the next node to expand, while the query's tables are in cache
     });
     if (need_grids.load(std::memory_order_relaxed)) {
-      st = pp_wavefront_multi_finish(ctx);
-      if (st != PP_OK) return st;
+      // (the other lane's round in flight was launched on the bounded grids: whatever of it looked
+      // beyond the limit carries the mark and comes back here at that lane's turn)
+      const double pf = prof ? now_ms() : 0.0;
+      int32_t fst = pp_wavefront_multi_finish(ctx);
+      if (fst != PP_OK) return fst;
+      if (prof) fprintf(stderr, "[plan] heuristic grids completed during the search: %.1f ms\n", now_ms() - pf);
       h_bounded = false;
       eo.hobs = nullptr;
       need_grids.store(false, std::memory_order_relaxed);
-      for (uint32_t id : live_ids) Q[id].cache.clear();  // f costs from the bounded grids
+      for (size_t l = 0; l < nlanes; ++l)
+        for (uint32_t id : lanes[l].ids) Q[id].cache.clear();  // f costs from the bounded grids
     }
-    if (prof) p_apply[pc] += now_ms() - p3;
+    if (prof) p_apply[ln.pc] += now_ms() - p3;
+    return PP_OK;
+  };
+
+  for (size_t l = 0; l < nlanes; ++l) {
+    Lane& ln = lanes[l];
+    const double p0 = prof ? now_ms() : 0.0;
+    ln.emit.resize(ln.ids.size());
+    pool.run(ln.ids.size(), [&](size_t k) { advance_emit(ln, k); });
+    if (prof) p_adv[ln.ids.size() < 64 ? 1 : 0] += now_ms() - p0;
+  }
+  for (size_t l = 0; l < nlanes; ++l) {
+    st = launch(lanes[l]);
+    if (st != PP_OK) return st;
+  }
+  bool merged = nlanes == 1;
+  while (lanes[0].in_flight || lanes[1].in_flight) {
+    for (size_t l = 0; l < nlanes; ++l) {
+      Lane& ln = lanes[l];
+      st = collect(ln);
+      if (st != PP_OK) return st;
+      // few queries left: one lane again (a round of a handful of nodes is latency, not work, and
+      // the look-ahead shares its budget over one lane's queries)
+      if (!merged && l == 0 && lanes[0].ids.size() + lanes[1].ids.size() < kLaneMergeBelow) {
+        st = collect(lanes[1]);
+        if (st != PP_OK) return st;
+        Lane& o = lanes[1];
+        for (size_t k = 0; k < o.ids.size(); ++k)
+          if (o.emit[k].alive) {
+            ln.ids.push_back(o.ids[k]);
+            ln.emit.push_back(o.emit[k]);
+          }
+        o.ids.clear();
+        o.emit.clear();
+        merged = true;
+      }
+      if (merged && l == 1) continue;
+      st = launch(ln);
+      if (st != PP_OK) return st;
+    }
   }
   const double t_search = now_ms();
   if (prof)

@@ -221,6 +221,45 @@ def test_plan_batch_many_queries_on_a_large_map_vs_oracle(ctx):
         O.set_max_expansions(0)
 
 
+def test_large_batch_in_two_lanes_equals_small_batches_and_oracle(ctx):
+    """From 1024 queries on a batch runs as two lanes that alternate between host and device and
+    merge into one when few queries are left.  Every query must come out as it does in batches
+    below that size (one lane), and a sample of them as the CPU oracle has it; the map is dense
+    enough for many searches to outlive the merge."""
+    occ = W.plan_map(1024, 0.02)
+    ox, oy = W.raster_to_points(occ)
+    m = api.ObstacleMap(ctx, raster=occ)
+    cs, cg = W.plan_queries(6000, 1024, 16, min_dist=20.0, max_dist=150.0)
+    fs = api.collision_flags(ctx, m, CONF, cs[:, 0], cs[:, 1], cs[:, 2])
+    fg = api.collision_flags(ctx, m, CONF, cg[:, 0], cg[:, 1], cg[:, 2])
+    inside = (cs[:, 0] > 8) & (cs[:, 0] < 1015) & (cs[:, 1] > 8) & (cs[:, 1] < 1015)
+    keep = np.nonzero(inside & (fs == 0) & (fg == 0))[0][:1500]
+    assert len(keep) == 1500
+    starts, goals = cs[keep], cg[keep]
+    ctx.set_max_expansions(400)
+    O.set_max_expansions(400)
+    try:
+        big = api.plan_batch(ctx, m, CONF, starts, goals, cap=2048, closed_cap=400)
+        big = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in big.items()}
+        big_exp = np.array([int(s.expansions) for s in big["stats"]])
+        assert (big_exp > 40).sum() > 100, "too few long searches to exercise the merged lane"
+        for lo in range(0, 1500, 500):
+            part = api.plan_batch(ctx, m, CONF, starts[lo:lo + 500], goals[lo:lo + 500], cap=2048, closed_cap=400)
+            sl = slice(lo, lo + 500)
+            for k in ("status", "len", "cost", "x", "y", "yaw", "dir", "closed"):
+                assert np.array_equal(big[k][sl], part[k], equal_nan=True), (lo, k)
+            assert np.array_equal(big_exp[sl], [int(s.expansions) for s in part["stats"]])
+        om = O.OracleMap(ox, oy)
+        differ = 0
+        for i in list(range(0, 1500, 47)) + list(np.argsort(big_exp)[-8:]):
+            e = om.plan(CONF, starts[i], goals[i])
+            differ += not same_batch_query(big, int(i), e, 400)
+        assert differ <= 1, differ
+    finally:
+        ctx.set_max_expansions(100000)
+        O.set_max_expansions(0)
+
+
 def test_bounded_heuristic_grids_do_not_change_a_search(ctx):
     """The planner relaxes its heuristic grids only up to a cost limit and completes them when a
     search looks beyond it.  Whatever the limit (pp_ctx_set_heuristic_limit overrides the planner's

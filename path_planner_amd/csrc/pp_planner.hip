@@ -1172,51 +1172,49 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     }
     q.st.rs_final_length = rtotal[k];
     const SNode& fp = q.nodes[q.final_parent];
-    // reversed accumulation exactly as the reference builds it, then one final reverse
-    std::vector<double> X, Y, YAW;
-    std::vector<int64_t> D;
+    // The reference accumulates the path backwards (the analytic node's points, then each
+    // rollout list, then the start point) and reverses it once; here every point goes straight to
+    // its final slot.
+    const uint64_t n_rs = f.with_final ? rnp_k - 1 : 0;
+    const size_t L = (size_t)n_rs + (size_t)f.nroll * (pts - 1) + 1;
     double cost = 0.0;
+    if (f.with_final) cost += fp.cost + q.final_rs_cost;  // fcost = n_curr.cost + rs cost (:357)
+    for (uint32_t r = 0; r < f.nroll; ++r) cost += q.nodes[f.chain[r]].cost;
+    const SNode& ns = q.nodes[f.chain.back()];
+    cost += ns.cost;
+    po.len = L;
+    po.cost = cost;
+    if (po.cap < L || !po.x || !po.y || !po.yaw || !po.direction) {
+      q.status = PP_ERR_CAPACITY;
+      return;
+    }
+    size_t at = L;  // slots [at, L) are filled
     if (f.with_final) {
       const size_t a = roff[k];
-      for (uint64_t j = rnp_k; j-- > 1;) {  // node.x[1..].rev() of the RS node
-        X.push_back(rx[a + j]);
-        Y.push_back(ry[a + j]);
-        YAW.push_back(ryaw[a + j]);
-        D.push_back(rdir[a + j]);
+      for (uint64_t j = rnp_k; j-- > 1;) {  // node.x[1..] of the RS node
+        --at;
+        po.x[at] = rx[a + j];
+        po.y[at] = ry[a + j];
+        po.yaw[at] = ryaw[a + j];
+        po.direction[at] = rdir[a + j];
       }
-      cost += fp.cost + q.final_rs_cost;  // fcost = n_curr.cost + rs cost (:357)
     }
     for (uint32_t r = 0; r < f.nroll; ++r) {
       const SNode& n = q.nodes[f.chain[r]];
       const size_t a = (size_t)(f.roll0 + r) * pts;
       for (uint32_t j = pts; j-- > 1;) {
-        X.push_back(lx[a + j]);
-        Y.push_back(ly[a + j]);
-        YAW.push_back(lyaw[a + j]);
-        D.push_back(n.direction);
+        --at;
+        po.x[at] = lx[a + j];
+        po.y[at] = ly[a + j];
+        po.yaw[at] = lyaw[a + j];
+        po.direction[at] = n.direction;
       }
-      cost += n.cost;
     }
-    const SNode& ns = q.nodes[f.chain.back()];
-    X.push_back(ns.x);
-    Y.push_back(ns.y);
-    YAW.push_back(ns.yaw);
-    D.push_back(1);
-    cost += ns.cost;
-    po.len = X.size();
-    po.cost = cost;
-    if (po.cap < X.size() || !po.x || !po.y || !po.yaw || !po.direction) {
-      q.status = PP_ERR_CAPACITY;
-    } else {
-      const size_t L = X.size();
-      for (size_t j = 0; j < L; ++j) {
-        po.x[j] = X[L - 1 - j];
-        po.y[j] = Y[L - 1 - j];
-        po.yaw[j] = YAW[L - 1 - j];
-        po.direction[j] = D[L - 1 - j];
-      }
-      q.status = PP_OK;
-    }
+    po.x[0] = ns.x;
+    po.y[0] = ns.y;
+    po.yaw[0] = ns.yaw;
+    po.direction[0] = 1;
+    q.status = PP_OK;
   });
   const double t_extract = now_ms();
   if (getenv("PP_PLAN_PROFILE"))

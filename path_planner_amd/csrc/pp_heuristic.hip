@@ -211,6 +211,19 @@ __device__ inline double tile_cell_value(const TileGrid& g, int64_t x, int64_t y
   return g.blk[(uint64_t)t * kBlk + blk_off((lx & 3u) * 4u + (ly & 3u), (lx >> 2) * 8u + (ly >> 2))];
 }
 
+// The same, and whether a visit of the cell's own tile could lower it (neither blocked nor a
+// source-only cell, inside the grid).
+__device__ inline double tile_cell_value(const TileGrid& g, int64_t x, int64_t y, bool& relaxable) {
+  relaxable = false;
+  if (x < 0 || y < 0 || x >= (int64_t)g.ntx * kTile || y >= (int64_t)g.nty * kTile)
+    return __longlong_as_double((long long)kInfBits);
+  const uint32_t t = (uint32_t)(x >> 5) * g.nty + (uint32_t)(y >> 5);
+  const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
+  const uint32_t k = (lx & 3u) * 4u + (ly & 3u), ln = (lx >> 2) * 8u + (ly >> 2);
+  relaxable = ((g.mask[(uint64_t)t * 64 + ln] >> k) & 0x10001u) == 0u;
+  return g.blk[(uint64_t)t * kBlk + blk_off(k, ln)];
+}
+
 // Dense -> blocked.  One wave per tile, consecutive waves take tiles that are consecutive in y so
 // the strided rows of the dense arrays are read in long runs.
 __global__ void __launch_bounds__(256)
@@ -356,11 +369,51 @@ constexpr uint32_t kSweepCap = PP_SWEEP_CAP;  // sweeps per visit (the mean visi
 #endif
 
 
+// Which neighbours the moved cells of one side of a lane's patch can still reach.  The lane's patch
+// lies on the tile's edge SIDE (0 x-lo, 1 x-hi, 2 y-lo, 3 y-hi); its four cells there have the six
+// ring cells r = 0..5 across the edge (tile coordinate o0 + r along the edge, -1 .. 64) as
+// neighbours, cell c next to r = c, c + 1, c + 2.  A moved cell v can lower ring cell r only if the
+// owner of r may relax it and fl(v + step) is below r's value -- as read at the start of the
+// visit, and the owner can only have lowered it since, so a "no" is final.  reach[] holds, per ring
+// cell, that value, or -1 where the owner may not relax the cell.  The lowest such v per neighbour
+// tile goes to wake_key[] (0..3 the sides, 4..7 the corners (lo,lo) (lo,hi) (hi,lo) (hi,hi)).
+template <int SIDE>
+__device__ __forceinline__ void edge_reach(const double (&e)[6][6], uint32_t chg, const double (*reach)[68],
+                                           int o0, double diag, unsigned long long* wake_key) {
+  const double INF = __longlong_as_double((long long)kInfBits);
+  double ring[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) ring[r] = reach[SIDE][o0 + r + 1];
+  double k_lo = INF, k_mid = INF, k_hi = INF;  // towards ring cell 0, 1..4, 5
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k = SIDE == 0 ? c : SIDE == 1 ? 12 + c : SIDE == 2 ? 4 * c : 4 * c + 3;
+    if (!((chg >> k) & 1u)) continue;
+    const double v = SIDE == 0 ? e[1][1 + c] : SIDE == 1 ? e[4][1 + c] : SIDE == 2 ? e[1 + c][1] : e[1 + c][4];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int r = c + d;
+      if (v + (d == 1 ? 1.0 : diag) < ring[r]) {
+        if (r == 0) k_lo = pp_min_f64(k_lo, v);
+        else if (r == 5) k_hi = pp_min_f64(k_hi, v);
+        else k_mid = pp_min_f64(k_mid, v);
+      }
+    }
+  }
+  // ring cells 0 and 5 belong to a corner tile when they lie beyond the tile's own extent
+  const int corner_lo = SIDE == 0 ? 4 : SIDE == 1 ? 6 : SIDE == 2 ? 4 : 5;
+  const int corner_hi = SIDE == 0 ? 5 : SIDE == 1 ? 7 : SIDE == 2 ? 6 : 7;
+  if (k_mid < INF) atomicMin(&wake_key[SIDE], (unsigned long long)__double_as_longlong(k_mid));
+  if (k_lo < INF) atomicMin(&wake_key[o0 < 0 ? corner_lo : SIDE], (unsigned long long)__double_as_longlong(k_lo));
+  if (k_hi < INF) atomicMin(&wake_key[o0 + 5 > kSTile - 1 ? corner_hi : SIDE], (unsigned long long)__double_as_longlong(k_hi));
+}
+
 __global__ void __launch_bounds__(256, PP_TILE_WAVES)
 k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
   __shared__ double lds[12 * kSSlot];
-  __shared__ uint32_t edge_bits;                 // which edges / corners of the tile moved
-  __shared__ unsigned long long edge_key;        // lowest value that moved on the tile's edge
+  __shared__ uint32_t edge_bits;                 // whether the slab's first / last owned column moved
+  __shared__ unsigned long long wake_key[8];     // per neighbour: lowest moved value that can still lower one of its cells
+  __shared__ double reach[4][68];                // per side: the ring cells' values where their owner may relax them, else -1 (index: offset along the edge + 1)
   __shared__ unsigned long long self_key;        // set when the sweeps were cut short
   __shared__ uint32_t act[3];                    // waves with work in sweep s at act[s % 3]
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -372,7 +425,7 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
   const int px = (int)(lane >> 3), py = (int)(lane & 7u);
   const double INF = __longlong_as_double((long long)kInfBits);
   const int own_slot = (qx * kPps + px + 1) * kSRow + (qy * kPps + py + 1);
-  unsigned long long blk_min = kInfBits;  // lowest key this workgroup handed out (thread 0)
+  unsigned long long blk_min = kInfBits;  // lowest key this thread handed out (threads 0..7)
   uint32_t visits = 0, sweeps_total = 0;
 
 #ifdef PP_LAB_PHASES
@@ -389,9 +442,9 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
     const bool have = bx < g.ntx && by < g.nty;  // the grid may end inside the scheduling tile
     const uint32_t blk_id = have ? bx * g.nty + by : 0u;
     double* blk = g.blk + (uint64_t)blk_id * kBlk;
+    if (tid < 8) wake_key[tid] = kInfBits;
     if (tid == 0) {
       edge_bits = 0;
-      edge_key = kInfBits;
       self_key = kInfBits;
       act[0] = 0;
       act[1] = 0;
@@ -425,19 +478,29 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
       if (r < 2 * (kSTile + 2)) {
         const int side = r >= kSTile + 2, o = (side ? r - (kSTile + 2) : r) - 1;  // o = -1 .. 64
         const int q = (o + 4) >> 2, j = (o + 4) & 3;
+        bool rel;
+        const double v = tile_cell_value(g, side ? X0 + kSTile : X0 - 1, Y0 + o, rel);
         if (!side)
-          lds[(4 + j) * kSSlot + 0 * kSRow + q] = tile_cell_value(g, X0 - 1, Y0 + o);                // slot (3, j)
+          lds[(4 + j) * kSSlot + 0 * kSRow + q] = v;                // slot (3, j)
         else
-          lds[j * kSSlot + (kSRing - 1) * kSRow + q] = tile_cell_value(g, X0 + kSTile, Y0 + o);      // slot (0, j)
+          lds[j * kSSlot + (kSRing - 1) * kSRow + q] = v;           // slot (0, j)
+        const double rv = rel ? v : -1.0;
+        reach[side][o + 1] = rv;
+        // the four corner cells are also the ends of the y sides' rows
+        if (o < 0) reach[2][side ? kSTile + 1 : 0] = rv;
+        if (o >= kSTile) reach[3][side ? kSTile + 1 : 0] = rv;
       } else {
         const int rr = r - 2 * (kSTile + 2);
         const int side = rr >= kSTile, o = side ? rr - kSTile : rr;  // o = 0 .. 63
         const int prow = (o >> 2) + 1, i = o & 3;
         const int s3 = i == 0 ? 3 : (i == 3 ? 7 : 9 + i), s0 = i == 0 ? 0 : (i == 3 ? 4 : 7 + i);
+        bool rel;
+        const double v = tile_cell_value(g, X0 + o, side ? Y0 + kSTile : Y0 - 1, rel);
         if (!side)
-          lds[s3 * kSSlot + prow * kSRow + 0] = tile_cell_value(g, X0 + o, Y0 - 1);                  // slot (i, 3)
+          lds[s3 * kSSlot + prow * kSRow + 0] = v;                  // slot (i, 3)
         else
-          lds[s0 * kSSlot + prow * kSRow + (kSRing - 1)] = tile_cell_value(g, X0 + o, Y0 + kSTile);  // slot (i, 0)
+          lds[s0 * kSSlot + prow * kSRow + (kSRing - 1)] = v;       // slot (i, 0)
+        reach[2 + side][o + 1] = rel ? v : -1.0;
       }
     }
     __syncthreads();
@@ -538,8 +601,7 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
 
     PP_PHASE(1);
     // write back what moved; cells on the tile's edge wake the neighbours that read them
-    uint32_t bits = 0;  // 0 x-lo, 1 x-hi, 2 y-lo, 3 y-hi, 4..7 corners (00, 01, 10, 11), 8 first col, 9 last col
-    double edge_min = INF;
+    uint32_t chg = 0;  // bit k: patch cell k moved
     if (have && moved_any) {  // a patch that never moved is not read back
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) {
@@ -552,49 +614,52 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
           const double v = e[i + 1][j + 1];
           if (__double_as_longlong(h ? old.y : old.x) != __double_as_longlong(v)) {
             any = true;
-            const int li = qx * kTile + 4 * px + i, lj = qy * kTile + 4 * py + j;
-            const bool xl = li == 0, xh = li == kSTile - 1, yl = lj == 0, yh = lj == kSTile - 1;
-            if (xl || xh || yl || yh) edge_min = pp_min_f64(edge_min, v);
-            bits |= (xl ? 1u : 0u) | (xh ? 2u : 0u) | (yl ? 4u : 0u) | (yh ? 8u : 0u);
-            bits |= (xl && yl ? 16u : 0u) | (xl && yh ? 32u : 0u) | (xh && yl ? 64u : 0u) | (xh && yh ? 128u : 0u);
-            bits |= ((uint64_t)(X0 + li) == w.own_first ? 256u : 0u) | ((uint64_t)(X0 + li) == w.own_last ? 512u : 0u);
+            chg |= 1u << k;
+            const uint64_t col = (uint64_t)(X0 + qx * kTile + 4 * px + i);
+            if (col == w.own_first) atomicOr(&edge_bits, 256u);
+            if (col == w.own_last) atomicOr(&edge_bits, 512u);
           }
         }
         if (any) *p = make_double2(e[(2 * k2) / 4 + 1][(2 * k2) % 4 + 1], e[(2 * k2 + 1) / 4 + 1][(2 * k2 + 1) % 4 + 1]);
       }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      bits |= __shfl_xor(bits, off);
-      edge_min = pp_min_f64(edge_min, __shfl_xor(edge_min, off));
-    }
-    if (lane == 0 && bits) {
-      atomicOr(&edge_bits, bits);
-      atomicMin(&edge_key, (unsigned long long)__double_as_longlong(edge_min));
+    // moved cells on the tile's edge: which neighbours can they still reach
+    if (__ballot(chg != 0u) != 0ull) {
+      if (qx == 0) {
+        if (px == 0 && (chg & 0x000Fu)) edge_reach<0>(e, chg, reach, qy * kTile + 4 * py - 1, diag, wake_key);
+      } else {
+        if (px == kPps - 1 && (chg & 0xF000u)) edge_reach<1>(e, chg, reach, qy * kTile + 4 * py - 1, diag, wake_key);
+      }
+      if (qy == 0) {
+        if (py == 0 && (chg & 0x1111u)) edge_reach<2>(e, chg, reach, qx * kTile + 4 * px - 1, diag, wake_key);
+      } else {
+        if (py == kPps - 1 && (chg & 0x8888u)) edge_reach<3>(e, chg, reach, qx * kTile + 4 * px - 1, diag, wake_key);
+      }
     }
     __syncthreads();
-    const uint32_t eb = edge_bits;
-    const unsigned long long ek = edge_key;
-    // threads 0..7 wake one neighbour each
+    // threads 0..7 look after one neighbour each
     if (tid < 8) {
       const int ddx = tid < 3 ? -1 : (tid < 5 ? 0 : 1);
       const int ddy = (tid == 0 || tid == 3 || tid == 5) ? -1 : ((tid == 2 || tid == 4 || tid == 7) ? 1 : 0);
-      const uint32_t need = tid == 0 ? 16u : tid == 1 ? 1u : tid == 2 ? 32u : tid == 3 ? 4u
-                          : tid == 4 ? 8u : tid == 5 ? 64u : tid == 6 ? 2u : 128u;
-      if (eb & need) tile_wake(g, w, (int64_t)tx + ddx, (int64_t)ty + ddy, ek);
+      const int nb = tid == 0 ? 4 : tid == 1 ? 0 : tid == 2 ? 5 : tid == 3 ? 2 : tid == 4 ? 3 : tid == 5 ? 6 : tid == 6 ? 1 : 7;
+      const unsigned long long wk = wake_key[nb];
+      if (wk != kInfBits) {
+        tile_wake(g, w, (int64_t)tx + ddx, (int64_t)ty + ddy, wk);
+        blk_min = min(blk_min, wk);
+      }
     }
     if (tid == 0 && self_key != kInfBits) {
       tile_wake(g, w, (int64_t)tx, (int64_t)ty, self_key);
       blk_min = min(blk_min, self_key);
     }
     if (tid == 0) {
-      if (eb & 15u) blk_min = min(blk_min, ek);
+      const uint32_t eb = edge_bits;
       if (eb & 256u) w.status[2] = 1;
       if (eb & 512u) w.status[3] = 1;
       ++visits;
       sweeps_total += sweeps;
     }
-    __syncthreads();  // edge_bits / edge_key and the LDS rims are reused by the next tile
+    __syncthreads();  // the shared words and the LDS rims are reused by the next tile
     PP_PHASE(2);
   }
 #ifdef PP_LAB_PHASES
@@ -603,8 +668,8 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
     for (int k = 0; k < 3; ++k) atomicAdd(&prof[k], ph[k]);
   }
 #endif
+  if (tid < 8 && blk_min != kInfBits) atomicMin(&w.minkey[(round + 1) % 3], blk_min);
   if (tid == 0 && visits) {
-    if (blk_min != kInfBits) atomicMin(&w.minkey[(round + 1) % 3], blk_min);
     atomicAdd(&w.status[0], visits);
     atomicAdd(&w.status[1], sweeps_total);
   }

@@ -311,15 +311,17 @@ __global__ void __launch_bounds__(256) k_tile_list(TileGrid g, TileWork w, uint3
     w.count[(round + 1) % 3] = 0;
     w.minkey[(round + 2) % 3] = kInfBits;
   }
+  // the key is fetched alongside the bitmap word, not after it: a round waits for this kernel
   const uint32_t word = t < w.ntiles ? w.bitmap[t >> 5] : 0u;
+  unsigned long long kb = t < w.ntiles ? w.key[t] : kInfBits;
   const bool woken = (word >> (t & 31u)) & 1u;
   if (__ballot(woken) == 0ull) return;  // wave-uniform
   bool take = false;
-  unsigned long long kb = kInfBits;
   if (woken) {
-    kb = w.key[t];
     const double kv = __longlong_as_double((long long)kb);
     take = !(kv > theta) && !(kv > w.limit);
+  } else {
+    kb = kInfBits;
   }
   // the 32 lanes that share a bitmap word clear their taken bits together
   const unsigned long long tb = __ballot(take);

@@ -163,6 +163,10 @@ __device__ inline bool dense_column(const DenseView& d, int64_t x, uint32_t& pla
 struct TileGrid {
   double* blk;           // tile t at blk + t * kBlk
   uint32_t* mask;        // mask[t * 64 + lane]: bit k = cell k blocked, bit 16 + k = cell k fixed
+  double* yrim;          // yrim[(t * 2 + s) * 32 + lx]: a copy of block t's rows ly = 0 (s = 0) and ly = 31 (s = 1),
+                         // kept current for the rows on a scheduling tile's edge (even block rows: s = 0, odd: s = 1).
+                         // In the block itself the 32 cells of such a row sit in 32 different cache lines;
+                         // the tiles above and below read them from here
   uint32_t ntx, nty;     // 32x32 blocks over the stored columns
   uint32_t nsx, nsy;     // scheduling tiles: 2x2 blocks = 64x64 cells, one workgroup each
 };
@@ -224,6 +228,23 @@ __device__ inline double tile_cell_value(const TileGrid& g, int64_t x, int64_t y
   return g.blk[(uint64_t)t * kBlk + blk_off(k, ln)];
 }
 
+// Every store to a cell of row ly = 0 or 31 of a block is repeated in the block's row copy.
+__device__ inline void tile_yrim_store(const TileGrid& g, uint32_t t, uint32_t lx, uint32_t ly, double v) {
+  if (ly == 0u) g.yrim[((uint64_t)t * 2) * 32 + lx] = v;
+  if (ly == 31u) g.yrim[((uint64_t)t * 2 + 1) * 32 + lx] = v;
+}
+// tile_cell_value for a cell of such a row, read from the copy.
+__device__ inline double tile_yrim_value(const TileGrid& g, int64_t x, int64_t y, bool& relaxable) {
+  relaxable = false;
+  if (x < 0 || y < 0 || x >= (int64_t)g.ntx * kTile || y >= (int64_t)g.nty * kTile)
+    return __longlong_as_double((long long)kInfBits);
+  const uint32_t t = (uint32_t)(x >> 5) * g.nty + (uint32_t)(y >> 5);
+  const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
+  const uint32_t k = (lx & 3u) * 4u + (ly & 3u), ln = (lx >> 2) * 8u + (ly >> 2);
+  relaxable = ((g.mask[(uint64_t)t * 64 + ln] >> k) & 0x10001u) == 0u;
+  return g.yrim[((uint64_t)t * 2 + (ly ? 1u : 0u)) * 32 + lx];
+}
+
 // Dense -> blocked.  One wave per tile, consecutive waves take tiles that are consecutive in y so
 // the strided rows of the dense arrays are read in long runs.
 __global__ void __launch_bounds__(256)
@@ -266,6 +287,12 @@ k_tile_pack(DenseView d, TileGrid g, uint32_t ntiles, int init_inf) {
     for (int k2 = 0; k2 < 8; ++k2)
       *(double2*)(b + blk_off(2 * k2, lane)) = make_double2(v[2 * k2], v[2 * k2 + 1]);
     g.mask[(uint64_t)t * 64 + lane] = m;
+    if (py == 0u || py == 7u) {  // the block's first / last row
+      double* yr = g.yrim + ((uint64_t)t * 2 + (py ? 1u : 0u)) * 32 + 4 * px;
+      const int j = py ? 3 : 0;
+      *(double2*)yr = make_double2(v[0 * 4 + j], v[1 * 4 + j]);
+      *(double2*)(yr + 2) = make_double2(v[2 * 4 + j], v[3 * 4 + j]);
+    }
   }
 }
 
@@ -497,7 +524,7 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
         const int prow = (o >> 2) + 1, i = o & 3;
         const int s3 = i == 0 ? 3 : (i == 3 ? 7 : 9 + i), s0 = i == 0 ? 0 : (i == 3 ? 4 : 7 + i);
         bool rel;
-        const double v = tile_cell_value(g, X0 + o, side ? Y0 + kSTile : Y0 - 1, rel);
+        const double v = tile_yrim_value(g, X0 + o, side ? Y0 + kSTile : Y0 - 1, rel);
         if (!side)
           lds[s3 * kSSlot + prow * kSRow + 0] = v;                  // slot (i, 3)
         else
@@ -625,6 +652,18 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
         if (any) *p = make_double2(e[(2 * k2) / 4 + 1][(2 * k2) % 4 + 1], e[(2 * k2 + 1) / 4 + 1][(2 * k2 + 1) % 4 + 1]);
       }
     }
+    // the copies of the rows on the tile's y edges (the only ones other tiles read; the two rows
+    // where the tile's blocks meet are left as they are): the lane's four cells in one piece
+    if (qy == 0 && py == 0 && (chg & 0x1111u)) {
+      double* yr = g.yrim + ((uint64_t)blk_id * 2) * 32 + 4 * px;
+      *(double2*)yr = make_double2(e[1][1], e[2][1]);
+      *(double2*)(yr + 2) = make_double2(e[3][1], e[4][1]);
+    }
+    if (qy == 1 && py == kPps - 1 && (chg & 0x8888u)) {
+      double* yr = g.yrim + ((uint64_t)blk_id * 2 + 1) * 32 + 4 * px;
+      *(double2*)yr = make_double2(e[1][4], e[2][4]);
+      *(double2*)(yr + 2) = make_double2(e[3][4], e[4][4]);
+    }
     // moved cells on the tile's edge: which neighbours can they still reach
     if (__ballot(chg != 0u) != 0ull) {
       if (qx == 0) {
@@ -688,6 +727,7 @@ __global__ void k_seed_goal(TileGrid g, TileWork w, int64_t x, int64_t y) {
   const uint32_t t = (uint32_t)(x >> 5) * g.nty + (uint32_t)(y >> 5);
   const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
   g.blk[(uint64_t)t * kBlk + blk_off((lx & 3u) * 4u + (ly & 3u), (lx >> 2) * 8u + (ly >> 2))] = 0.0;
+  tile_yrim_store(g, t, lx, ly, 0.0);
   tile_wake(g, w, x >> 6, y >> 6, 0ull);
   atomicMin(&w.minkey[0], 0ull);
 }
@@ -700,6 +740,7 @@ __global__ void k_seed_goals(TileGrid g, TileWork w, uint32_t planes, uint64_t p
   const uint32_t t = (uint32_t)(x >> 5) * g.nty + (uint32_t)(y >> 5);
   const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
   g.blk[(uint64_t)t * kBlk + blk_off((lx & 3u) * 4u + (ly & 3u), (lx >> 2) * 8u + (ly >> 2))] = 0.0;
+  tile_yrim_store(g, t, lx, ly, 0.0);
   tile_wake(g, w, x >> 6, y >> 6, 0ull);
   if (p == 0) atomicMin(&w.minkey[0], 0ull);
 }
@@ -747,6 +788,7 @@ __global__ void k_slab_take_halo(TileGrid g, TileWork w, uint64_t yw, uint64_t c
     const double v = src[y];
     if (v < *cell) {
       *cell = v;
+      tile_yrim_store(g, t, lx, ly, v);
       const unsigned long long kb = (unsigned long long)__double_as_longlong(v);
       for (int dx = -1; dx <= 1; ++dx)
         for (int dy = -1; dy <= 1; ++dy) {
@@ -808,8 +850,9 @@ int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run, void** own_b
   if (nblocks == 0 || nblocks >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t b_blk = al(nblocks * kBlk * 8), b_mask = al(nblocks * 64 * 4), b_list = al(ntiles * 4);
+  const size_t b_yrim = al(nblocks * 2 * 32 * 8);
   const size_t b_bits = al(((ntiles + 63) / 64) * 8), b_key = al(ntiles * 8), b_misc = 256;
-  const size_t need = b_blk + b_mask + b_list + b_bits + b_key + b_misc;
+  const size_t need = b_blk + b_mask + b_yrim + b_list + b_bits + b_key + b_misc;
   if (need > wbytes) {
     if (wbuf) PP_HIP(ctx, hipFree(wbuf));
     wbuf = nullptr;
@@ -822,6 +865,8 @@ int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run, void** own_b
   b += b_blk;
   run->g.mask = (uint32_t*)b;
   b += b_mask;
+  run->g.yrim = (double*)b;
+  b += b_yrim;
   run->g.ntx = (uint32_t)ntx;
   run->g.nty = (uint32_t)nty;
   run->g.nsx = (uint32_t)nsx;

@@ -260,6 +260,36 @@ def test_large_batch_in_two_lanes_equals_small_batches_and_oracle(ctx):
         O.set_max_expansions(0)
 
 
+def test_two_lanes_with_failing_queries(ctx):
+    """A large batch on the demo map in which most queries fail one way or another (goal outside
+    the heuristic grid, start on the goal, start in collision, expansion cap): per-query status,
+    counters and closing order as in batches small enough for one lane."""
+    ox, oy = W.demo_obstacles()
+    m = api.ObstacleMap(ctx, ox, oy)
+    rng = np.random.default_rng(31)
+    n = 1100
+    starts = np.column_stack([rng.uniform(4, 46, n), rng.uniform(4, 26, n), rng.uniform(-3, 3, n)])
+    goals = np.column_stack([rng.uniform(4, 46, n), rng.uniform(4, 26, n), rng.uniform(-3, 3, n)])
+    goals[::7] = [60.0, 20.0, 0.0]            # outside the grid: the reference panics on hmap indexing
+    goals[3::11] = starts[3::11]              # start == goal: Reeds-Shepp assert
+    starts[5::13] = [25.0, 8.0, 0.0]          # unreachable goal behind the wall: runs into the cap
+    goals[5::13] = [45.0, 28.5, 0.0]
+    ctx.set_max_expansions(120)
+    try:
+        big = api.plan_batch(ctx, m, CONF, starts, goals, cap=1024, closed_cap=120)
+        exp_big = np.array([int(s.expansions) for s in big["stats"]])
+        seen = set(int(v) for v in big["status"])
+        assert {A.PP_OK, A.PP_ERR_BOUNDS, A.PP_ERR_DEGENERATE_RS, A.PP_ERR_LIMIT} <= seen, seen
+        for lo in range(0, n, 275):
+            part = api.plan_batch(ctx, m, CONF, starts[lo:lo + 275], goals[lo:lo + 275], cap=1024, closed_cap=120)
+            sl = slice(lo, lo + 275)
+            for k in ("status", "len", "cost", "x", "y", "yaw", "dir", "closed"):
+                assert np.array_equal(big[k][sl], part[k], equal_nan=True), (lo, k)
+            assert np.array_equal(exp_big[sl], [int(s.expansions) for s in part["stats"]])
+    finally:
+        ctx.set_max_expansions(100000)
+
+
 def test_bounded_heuristic_grids_do_not_change_a_search(ctx):
     """The planner relaxes its heuristic grids only up to a cost limit and completes them when a
     search looks beyond it.  Whatever the limit (pp_ctx_set_heuristic_limit overrides the planner's

@@ -96,8 +96,9 @@ __global__ void k_obsmap(uint64_t n, const double* __restrict__ ox, const double
 //   d[goal] = 0,  d[v] = min over valid neighbours n of fl(d[n] + w(n, v)),  w in {1, hypot(1,1)}
 // (each fl(d + w) is monotone in d, so relaxing from any upper bounds in any order converges to the
 // same bits).  The grid is cut into 64x64-cell tiles; a round relaxes every listed tile to its
-// own fixpoint against the current values of the surrounding ring of cells, and a tile whose edge
-// cells moved wakes the neighbours that see them.  One workgroup of four waves owns one tile, a
+// own fixpoint against the current values of the surrounding ring of cells, and a tile wakes a
+// neighbour when one of its edge cells moved to a value that can still lower a cell of that
+// neighbour.  One workgroup of four waves owns one tile, a
 // wave one 32x32 quadrant of it: each lane keeps a 4x4 patch in registers and sweeps it forward
 // and backward (a two-pass chamfer transform), the patches trade rim values through LDS, and the
 // workgroup repeats until no cell moves.  A value crosses one patch per sweep, so the cost of a
@@ -112,8 +113,10 @@ __global__ void k_obsmap(uint64_t n, const double* __restrict__ ox, const double
 //
 // Working layout: costs live in a blocked array, one contiguous 8 KiB block per 32x32 quadrant
 // with the 16 cells of a lane's patch interleaved across lanes (so every load is a coalesced 1 KiB), and
-// the obstacle raster is folded into one mask word per lane.  The caller's dense x-major arrays
-// are packed into that layout before the rounds and unpacked after them.
+// the obstacle raster is folded into one mask word per lane.  The cells of a block's first and
+// last row sit in 32 different cache lines there, so each block also keeps a compact copy of those
+// two rows for the tiles above and below to read.  The caller's dense x-major arrays are packed
+// into that layout before the rounds and unpacked after them.
 
 constexpr int kTile = 32;                    // cells per block side (one wave's quadrant of a tile)
 constexpr int kPps = 8;                      // 4x4 patches per block side

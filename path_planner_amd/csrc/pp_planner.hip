@@ -1029,6 +1029,11 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     return PP_OK;
   };
 
+  // leaving with an error: the other lane's round may still be running on the staging buffers
+  auto drain = [&](int32_t code) {
+    (void)hipStreamSynchronize(s);
+    return code;
+  };
   for (size_t l = 0; l < nlanes; ++l) {
     Lane& ln = lanes[l];
     const double p0 = prof ? now_ms() : 0.0;
@@ -1038,19 +1043,19 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   }
   for (size_t l = 0; l < nlanes; ++l) {
     st = launch(lanes[l]);
-    if (st != PP_OK) return st;
+    if (st != PP_OK) return drain(st);
   }
   bool merged = nlanes == 1;
   while (lanes[0].in_flight || lanes[1].in_flight) {
     for (size_t l = 0; l < nlanes; ++l) {
       Lane& ln = lanes[l];
       st = collect(ln);
-      if (st != PP_OK) return st;
+      if (st != PP_OK) return drain(st);
       // few queries left: one lane again (a round of a handful of nodes is latency, not work, and
       // the look-ahead shares its budget over one lane's queries)
       if (!merged && l == 0 && lanes[0].ids.size() + lanes[1].ids.size() < kLaneMergeBelow) {
         st = collect(lanes[1]);
-        if (st != PP_OK) return st;
+        if (st != PP_OK) return drain(st);
         Lane& o = lanes[1];
         for (size_t k = 0; k < o.ids.size(); ++k)
           if (o.emit[k].alive) {
@@ -1063,7 +1068,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       }
       if (merged && l == 1) continue;
       st = launch(ln);
-      if (st != PP_OK) return st;
+      if (st != PP_OK) return drain(st);
     }
   }
   const double t_search = now_ms();

@@ -220,8 +220,10 @@ class Pool {
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
-  void run(size_t n, const std::function<void(size_t)>& fn) {
+  // `chunk` = items a thread takes at a time: small for items that are work, large for trivial ones
+  void run(size_t n, const std::function<void(size_t)>& fn, size_t chunk = 16) {
     if (n == 0) return;
+    chunk_ = chunk;
     if (th_.empty() || n < 64) {
       for (size_t i = 0; i < n; ++i) fn(i);
       return;
@@ -259,9 +261,10 @@ class Pool {
   }
   void work() {
     for (;;) {
-      size_t i = next_.fetch_add(16);
+      const size_t c = chunk_;
+      size_t i = next_.fetch_add(c);
       if (i >= n_) break;
-      size_t e = std::min(n_, i + 16);
+      size_t e = std::min(n_, i + c);
       for (; i < e; ++i) (*fn_)(i);
     }
   }
@@ -288,7 +291,7 @@ class Pool {
   std::mutex m_;
   std::condition_variable cv_, done_;
   const std::function<void(size_t)>* fn_ = nullptr;
-  size_t n_ = 0;
+  size_t n_ = 0, chunk_ = 16;
   std::atomic<size_t> next_{0};
   std::atomic<size_t> pending_{0};
   std::atomic<uint64_t> gen_{0};
@@ -901,7 +904,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         hsteer[k] = e.steer;
         hcost[k] = e.cost;
         hhid[k] = e.hid;
-      });
+      }, 64);
     } else {
       pool.run(nl, [&](size_t li) {  // every query fills its own slots
         Query& q = Q[ln.ids[li]];
@@ -1011,7 +1014,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         q.curr = -1;
       }
       advance_emit(ln, k);  // the next node to expand, while the query's tables are in cache
-    });
+    }, 8);
     if (need_grids.load(std::memory_order_relaxed)) {
       // (the other lane's round in flight was launched on the bounded grids: whatever of it looked
       // beyond the limit carries the mark and comes back here at that lane's turn)

@@ -57,6 +57,8 @@ extern "C" void pp_ctx_destroy(pp_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->wave_resume && ctx->wave_resume_free) ctx->wave_resume_free(ctx->wave_resume);
   if (ctx->wave_buf) (void)hipFree(ctx->wave_buf);
+  if (ctx->wave_counts) (void)hipHostFree(ctx->wave_counts);
+  if (ctx->wave_event) (void)hipEventDestroy(ctx->wave_event);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->plan_buf) (void)hipFree(ctx->plan_buf);
   if (ctx->hmap_buf) (void)hipFree(ctx->hmap_buf);

@@ -898,27 +898,49 @@ int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run, void** own_b
   return PP_OK;
 }
 
-// Rounds until no tile is woken.  The host looks at the list length once per batch of rounds; a
-// round over an empty list costs two empty launches.
+// Rounds until no tile is woken.  The host reads the list lengths once per batch of rounds, and the
+// device is kept busy meanwhile: two rounds of the next batch are queued before the host waits for
+// the read-back (a wait plus the relaunch costs about as long as one or two rounds take), the rest
+// of the batch follows if the last batch ended with tiles still listed.  A round over an empty
+// list costs two empty launches.
 int32_t tile_run(pp_ctx* ctx, TileRun& run, uint64_t* rounds_out, uint32_t status_out[4]) {
   const double diag = std::hypot(1.0, 1.0);  // u_cost((+-1, +-1)), astar.rs:213-215
   const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus * PP_TILE_GRID, run.w.ntiles);
   const unsigned lgrid = (run.w.ntiles + 255) / 256;
+  if (!ctx->wave_counts) PP_HIP(ctx, hipHostMalloc((void**)&ctx->wave_counts, 64, hipHostMallocDefault));
+  if (!ctx->wave_event) PP_HIP(ctx, hipEventCreateWithFlags(&ctx->wave_event, hipEventDisableTiming));
   uint32_t round = run.round;
-  uint32_t counts[3];
-  uint32_t batch = 2;  // a slab session often has a round or two of work per call
-  for (;;) {
-    for (uint32_t j = 0; j < batch; ++j, ++round) {
+  auto enqueue = [&](uint32_t k) {
+    for (uint32_t j = 0; j < k; ++j, ++round) {
       hipLaunchKernelGGL(k_tile_list, dim3(lgrid), dim3(256), 0, ctx->stream, run.g, run.w, round);
       hipLaunchKernelGGL(k_tile_round, dim3(grid), dim3(256), 0, ctx->stream, run.g, run.w, round, diag);
     }
+  };
+#ifndef PP_RUN_AHEAD
+#define PP_RUN_AHEAD 2
+#endif
+#ifndef PP_RUN_BATCH_MAX
+#define PP_RUN_BATCH_MAX 64
+#endif
+  constexpr uint32_t kAhead = PP_RUN_AHEAD;
+  uint32_t batch = 2;  // a slab session often has a round or two of work per call
+  enqueue(batch);
+  for (;;) {
+    const uint32_t last = round - 1;  // the round whose list length decides
     PP_HIP(ctx, hipGetLastError());
-    PP_HIP(ctx, hipMemcpyAsync(counts, run.w.count, 12, hipMemcpyDeviceToHost, ctx->stream));
-    PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (counts[(round - 1) % 3] == 0) break;  // the last round found nothing woken
-    if (round > (1u << 30)) return PP_ERR_UNSUPPORTED;
-    batch = std::min<uint32_t>(batch * 2, 64);
+    PP_HIP(ctx, hipMemcpyAsync(ctx->wave_counts, run.w.count, 12, hipMemcpyDeviceToHost, ctx->stream));
+    PP_HIP(ctx, hipEventRecord(ctx->wave_event, ctx->stream));
+    enqueue(kAhead);
+    PP_HIP(ctx, hipEventSynchronize(ctx->wave_event));
+    if (ctx->wave_counts[last % 3] == 0) break;  // that round found nothing woken, nor do the two after it
+    if (round > (1u << 30)) {
+      (void)hipStreamSynchronize(ctx->stream);
+      return PP_ERR_UNSUPPORTED;
+    }
+    batch = std::min<uint32_t>(batch * 2, PP_RUN_BATCH_MAX);
+    enqueue(batch > kAhead ? batch - kAhead : 0);
   }
+  PP_HIP(ctx, hipGetLastError());
   PP_HIP(ctx, hipMemcpyAsync(status_out, run.w.status, 16, hipMemcpyDeviceToHost, ctx->stream));
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 #ifdef PP_LAB_PHASES

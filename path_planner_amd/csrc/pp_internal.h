@@ -79,6 +79,8 @@ struct pp_ctx {
   void* wave_resume = nullptr;  // state of a relaxation stopped at a cost limit (owned by pp_heuristic.hip)
   void (*wave_resume_free)(void*) = nullptr;
   uint64_t wave_stats[4] = {0, 0, 0, 0};  // last relaxation: rounds, tile visits, sweep pairs, tiles
+  uint32_t* wave_counts = nullptr;  // pinned: the round counters as last read back
+  hipEvent_t wave_event = nullptr;  // that read-back
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   // the planner's per-round device staging (grown on demand, never shrunk)

@@ -249,7 +249,9 @@ __device__ inline double tile_yrim_value(const TileGrid& g, int64_t x, int64_t y
 }
 
 // Dense -> blocked.  One wave per tile, consecutive waves take tiles that are consecutive in y so
-// the strided rows of the dense arrays are read in long runs.
+// the strided rows of the dense arrays are read in long runs.  A lane's patch is four runs of four
+// consecutive cells of a dense column: a run that lies inside the grid and is suitably aligned is
+// moved in one piece (a dword of the raster, two 16-byte pieces of the costs).
 __global__ void __launch_bounds__(256)
 k_tile_pack(DenseView d, TileGrid g, uint32_t ntiles, int init_inf) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -257,31 +259,63 @@ k_tile_pack(DenseView d, TileGrid g, uint32_t ntiles, int init_inf) {
   const double INF = __longlong_as_double((long long)kInfBits);
   for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * 4) {
     const uint32_t tx = t / g.nty, ty = t - tx * g.nty;
+    const int64_t y0 = (int64_t)ty * kTile + 4 * py;
     uint32_t m = 0;
     double v[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      const int64_t x = (int64_t)tx * kTile + 4 * px + i;
+      uint32_t plane = 0;
+      int64_t xl = 0;
+      const bool col = x < (int64_t)d.ncols && y0 < (int64_t)d.yw && dense_column(d, x, plane, xl);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[i * 4 + j] = INF;
+      if (!col) {
+        m |= 0xFu << (4 * i);
+        continue;
+      }
+      const uint64_t idx = (uint64_t)xl * d.yw + (uint64_t)y0;
+      const bool whole = y0 + 3 < (int64_t)d.yw;
+      const bool other = x < (int64_t)d.own_lo || x >= (int64_t)d.own_hi;  // another rank's column
+      if (!init_inf) {
+        const double* src = d.cost + plane * d.cost_stride + idx;
+        if (whole && (((uintptr_t)src) & 15u) == 0u) {
+          const double2 p0 = *(const double2*)src, p1 = *(const double2*)(src + 2);
+          v[i * 4] = p0.x;
+          v[i * 4 + 1] = p0.y;
+          v[i * 4 + 2] = p1.x;
+          v[i * 4 + 3] = p1.y;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (y0 + j < (int64_t)d.yw) v[i * 4 + j] = src[j];
+        }
+      }
+      uint32_t ob = 0;  // byte j: the raster's cell (x, y0 + j)
+      if (!other) {
+        const uint8_t* src = d.obs + idx;
+        if (whole && (((uintptr_t)src) & 3u) == 0u) {
+          ob = *(const uint32_t*)src;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (y0 + j < (int64_t)d.yw) ob |= (uint32_t)src[j] << (8 * j);
+        }
+      }
+      const int64_t gx = d.planes ? d.goals[2 * plane] : d.goal_x;
+      const int64_t gy = d.planes ? d.goals[2 * plane + 1] : d.goal_y;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int64_t x = (int64_t)tx * kTile + 4 * px + i, y = (int64_t)ty * kTile + 4 * py + j;
         const int k = i * 4 + j;
-        v[k] = INF;
-        uint32_t plane;
-        int64_t xl;
-        if (x < (int64_t)d.ncols && y < (int64_t)d.yw && dense_column(d, x, plane, xl)) {
-          const uint64_t idx = (uint64_t)xl * d.yw + (uint64_t)y;
-          if (!init_inf) v[k] = d.cost[plane * d.cost_stride + idx];
-          if (x < (int64_t)d.own_lo || x >= (int64_t)d.own_hi) {
-            m |= 1u << (16 + k);  // another rank's column: a source, never relaxed here
-          } else {
-            // check_node (astar.rs:200-211); the goal is inserted without it (astar.rs:155)
-            const bool blocked = d.obs[idx] != 0 || xl + d.gx_off <= 0 || y <= 0;
-            const int64_t gx = d.planes ? d.goals[2 * plane] : d.goal_x;
-            const int64_t gy = d.planes ? d.goals[2 * plane + 1] : d.goal_y;
-            if (blocked && !(xl == gx && y == gy)) m |= 1u << k;
-          }
-        } else {
+        const int64_t y = y0 + j;
+        if (y >= (int64_t)d.yw) {
           m |= 1u << k;
+        } else if (other) {
+          m |= 1u << (16 + k);  // a source, never relaxed here
+        } else {
+          // check_node (astar.rs:200-211); the goal is inserted without it (astar.rs:155)
+          const bool blocked = ((ob >> (8 * j)) & 0xFFu) != 0u || xl + d.gx_off <= 0 || y <= 0;
+          if (blocked && !(xl == gx && y == gy)) m |= 1u << k;
         }
       }
     }
@@ -305,6 +339,7 @@ __global__ void __launch_bounds__(256) k_tile_unpack(DenseView d, TileGrid g, ui
   const uint32_t px = lane >> 3, py = lane & 7u;
   for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * 4) {
     const uint32_t tx = t / g.nty, ty = t - tx * g.nty;
+    const int64_t y0 = (int64_t)ty * kTile + 4 * py;
     const double* b = g.blk + (uint64_t)t * kBlk;
     double v[16];
 #pragma unroll
@@ -315,13 +350,18 @@ __global__ void __launch_bounds__(256) k_tile_unpack(DenseView d, TileGrid g, ui
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      const int64_t x = (int64_t)tx * kTile + 4 * px + i;
+      uint32_t plane;
+      int64_t xl;
+      if (!(x < (int64_t)d.ncols && y0 < (int64_t)d.yw && dense_column(d, x, plane, xl))) continue;
+      double* dst = d.cost + plane * d.cost_stride + (uint64_t)xl * d.yw + (uint64_t)y0;
+      if (y0 + 3 < (int64_t)d.yw && (((uintptr_t)dst) & 15u) == 0u) {
+        *(double2*)dst = make_double2(v[i * 4], v[i * 4 + 1]);
+        *(double2*)(dst + 2) = make_double2(v[i * 4 + 2], v[i * 4 + 3]);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t x = (int64_t)tx * kTile + 4 * px + i, y = (int64_t)ty * kTile + 4 * py + j;
-        uint32_t plane;
-        int64_t xl;
-        if (x < (int64_t)d.ncols && y < (int64_t)d.yw && dense_column(d, x, plane, xl))
-          d.cost[plane * d.cost_stride + (uint64_t)xl * d.yw + (uint64_t)y] = v[i * 4 + j];
+        for (int j = 0; j < 4; ++j)
+          if (y0 + j < (int64_t)d.yw) dst[j] = v[i * 4 + j];
       }
     }
   }

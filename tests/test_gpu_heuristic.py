@@ -100,6 +100,35 @@ def test_wavefront_vs_oracle(ctx, n, p, kind):
     assert iters > 0
 
 
+@pytest.mark.parametrize("xw,yw", [(1, 1), (1, 7), (5, 1), (2, 2), (33, 65), (65, 33), (130, 67), (3, 200),
+                                   (64, 64), (63, 66), (129, 128)])
+def test_wavefront_ragged_shapes_vs_oracle(ctx, xw, yw):
+    """Grids smaller than a tile, sides that are not multiples of the 4-cell patch or the 32-cell
+    block, odd row lengths (the dense arrays' rows are then not 16-byte aligned), and a view that
+    starts 8 bytes into an allocation."""
+    import torch
+    u = W.uniform01(1234 + xw * 1000 + yw, 0, xw * yw).reshape(xw, yw)
+    obs = (u < 0.2).astype(np.uint8)
+    gx, gy = xw // 2, yw // 2
+    obs[gx, gy] = 0
+    d_obs = torch.from_numpy(obs).cuda()
+    st, exp = O.wavefront(obs, gx, gy)
+    assert st == 0
+    cost = torch.empty((xw, yw), dtype=torch.float64, device="cuda")
+    api.wavefront_dev(ctx, d_obs, gx, gy, cost)
+    ctx.synchronize()
+    same_grid(cost.cpu().numpy(), exp)
+    # the same through misaligned views: costs 8 bytes, raster 1 byte into their allocations
+    flat = torch.empty(xw * yw + 1, dtype=torch.float64, device="cuda")
+    oflat = torch.empty(xw * yw + 1, dtype=torch.uint8, device="cuda")
+    c2, o2 = flat[1:].view(xw, yw), oflat[1:].view(xw, yw)
+    o2.copy_(d_obs)
+    torch.cuda.synchronize()  # the library works on its own stream
+    api.wavefront_dev(ctx, o2, gx, gy, c2)
+    ctx.synchronize()
+    same_grid(c2.cpu().numpy(), exp)
+
+
 def test_wavefront_goal_on_obstacle_and_border_and_errors(ctx):
     import torch
     obs, gx, gy = W.wavefront_obsmap(64, 0.2)

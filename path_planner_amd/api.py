@@ -51,6 +51,10 @@ class Context:
         """Cost limit (cells) of plan_batch's first heuristic relaxation; negative = automatic."""
         _chk(self.lib.pp_ctx_set_heuristic_limit(self.h, float(limit)), "pp_ctx_set_heuristic_limit")
 
+    def set_heuristic_workspace(self, nbytes):
+        """Memory budget of plan_batch's joint heuristic relaxation (default 8 GiB)."""
+        _chk(self.lib.pp_ctx_set_heuristic_workspace(self.h, int(nbytes)), "pp_ctx_set_heuristic_workspace")
+
     def synchronize(self):
         _chk(self.lib.pp_ctx_synchronize(self.h), "pp_ctx_synchronize")
 

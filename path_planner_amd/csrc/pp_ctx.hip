@@ -93,6 +93,12 @@ extern "C" int32_t pp_ctx_set_heuristic_limit(pp_ctx* ctx, double limit) {
   return PP_OK;
 }
 
+extern "C" int32_t pp_ctx_set_heuristic_workspace(pp_ctx* ctx, uint64_t bytes) {
+  if (!ctx) return PP_ERR_INVALID;
+  ctx->heuristic_pass_blocks = std::max<uint64_t>(1, bytes / 8192);
+  return PP_OK;
+}
+
 extern "C" int32_t pp_last_hip_error(pp_ctx* ctx) { return ctx ? ctx->last_hip_error : 0; }
 
 int32_t pp_scratch_reserve(pp_ctx* ctx, size_t bytes) {

@@ -1046,11 +1046,13 @@ extern "C" int32_t pp_wavefront_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const
 // every cell whose final value is at most the limit has it, the others hold an upper bound or
 // +inf.  The working state stays in the context and pp_wavefront_multi_finish completes the grids;
 // *bounded tells the caller whether that is the case.
-static uint32_t multi_per_pass(uint64_t xw, uint64_t yw, uint32_t n) {
+static uint32_t multi_per_pass(const pp_ctx* ctx, uint64_t xw, uint64_t yw, uint32_t n) {
   const uint64_t plane_tiles = ((xw + 1 + kTile - 1) / kTile + 1) * ((yw + kTile - 1) / kTile);
-  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, ((uint64_t)1 << 20) / plane_tiles));
+  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, ctx->heuristic_pass_blocks / plane_tiles));
 }
-bool pp_wavefront_multi_single_pass(uint64_t xw, uint64_t yw, uint32_t n) { return multi_per_pass(xw, yw, n) >= n; }
+bool pp_wavefront_multi_single_pass(const pp_ctx* ctx, uint64_t xw, uint64_t yw, uint32_t n) {
+  return multi_per_pass(ctx, xw, yw, n) >= n;
+}
 
 int32_t pp_wavefront_multi_finish(pp_ctx* ctx) {
   if (!ctx) return PP_ERR_INVALID;
@@ -1075,13 +1077,13 @@ int32_t pp_wavefront_multi_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint
                                const uint64_t* goal_x, const uint64_t* goal_y, double* d_cost,
                                uint64_t cost_stride, double limit, bool* bounded, PpBlockedGrids* keep_blocked) {
   if (bounded) *bounded = false;
-  if (keep_blocked && !pp_wavefront_multi_single_pass(xw, yw, n)) return PP_ERR_INVALID;
   if (!ctx || !d_obs || (!d_cost && !keep_blocked) || !goal_x || !goal_y) return PP_ERR_INVALID;
+  if (keep_blocked && !pp_wavefront_multi_single_pass(ctx, xw, yw, n)) return PP_ERR_INVALID;
   if (n == 0) return PP_OK;
   if (xw == 0 || yw == 0 || xw >= ((uint64_t)1 << 31) || yw >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
   PP_HIP(ctx, hipSetDevice(ctx->device));
   // planes per pass: keep the blocked working copy under ~8 GiB
-  const uint32_t per_pass = multi_per_pass(xw, yw, n);
+  const uint32_t per_pass = multi_per_pass(ctx, xw, yw, n);
   std::vector<int64_t> hg(2 * (size_t)per_pass);
   for (uint32_t p0 = 0; p0 < n; p0 += per_pass) {
     const uint32_t np = std::min(per_pass, n - p0);

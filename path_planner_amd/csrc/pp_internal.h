@@ -68,6 +68,7 @@ struct pp_ctx {
   int last_hip_error = 0;
   int num_cus = 256;
   uint64_t max_expansions = 100000;  // per query, 0 = unlimited
+  uint64_t heuristic_pass_blocks = (uint64_t)1 << 20;  // 32x32-cell blocks one relaxation of several grids may hold (8 KiB each)
   double heuristic_limit = -1.0;     // cost limit of the planner's first heuristic relaxation, < 0 = automatic
   // reusable device scratch (grown on demand, never shrunk)
   void* scratch = nullptr;
@@ -135,7 +136,7 @@ struct PpBlockedGrids {
   uint64_t plane_cols = 0;
 };
 // True when n grids of that size are relaxed in one pass (a precondition of keeping them blocked).
-bool pp_wavefront_multi_single_pass(uint64_t xw, uint64_t yw, uint32_t n);
+bool pp_wavefront_multi_single_pass(const pp_ctx* ctx, uint64_t xw, uint64_t yw, uint32_t n);
 int32_t pp_pinned_reserve(pp_ctx* ctx, size_t bytes);
 PpFootprint pp_make_footprint(const pp_config* conf);
 int32_t pp_check_config(const pp_config* conf);

@@ -411,7 +411,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   if (ngoals) {
     // Relaxed in one pass (the usual case), the grids stay in the relaxation's blocked working array
     // and the searches read them there; otherwise they are written out as dense arrays.
-    keep_blocked = pp_wavefront_multi_single_pass(hxw, hyw, (uint32_t)ngoals);
+    keep_blocked = pp_wavefront_multi_single_pass(ctx, hxw, hyw, (uint32_t)ngoals);
     const size_t b_hm = keep_blocked ? 0 : ngoals * al256(hcells * 8), b_obs = al256(hcells),
                  b_tab = al256(ngoals * sizeof(double*));
     if (b_hm + b_obs + b_tab > ctx->hmap_bytes) {

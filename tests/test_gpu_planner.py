@@ -319,3 +319,49 @@ def test_bounded_heuristic_grids_do_not_change_a_search(ctx):
     for lim, r in runs.items():
         for k, v in ref.items():
             assert np.array_equal(v, r[k], equal_nan=True), (lim, k)
+
+
+def test_heuristic_grids_in_several_passes(ctx):
+    """With a small memory budget (pp_ctx_set_heuristic_workspace) the heuristic grids of a batch's
+    goal cells are relaxed a few at a time and kept as dense arrays instead of the relaxation's own
+    layout: closing order, counters and paths are those of the one-pass run, and of the oracle."""
+    occ = W.plan_map(512, 0.01)
+    ox, oy = W.raster_to_points(occ)
+    m = api.ObstacleMap(ctx, raster=occ)
+    cs, cg = W.plan_queries(400, 512, 7, min_dist=10.0, max_dist=120.0)
+    fs = api.collision_flags(ctx, m, CONF, cs[:, 0], cs[:, 1], cs[:, 2])
+    fg = api.collision_flags(ctx, m, CONF, cg[:, 0], cg[:, 1], cg[:, 2])
+    inside = (cs[:, 0] > 8) & (cs[:, 0] < 503) & (cs[:, 1] > 8) & (cs[:, 1] < 503)
+    keep = np.nonzero(inside & (fs == 0) & (fg == 0))[0][:96]
+    starts, goals = cs[keep], cg[keep]
+    ngoals = len({(round(g[0] / CONF.xy_reso), round(g[1] / CONF.xy_reso)) for g in goals})
+    assert ngoals >= 5
+    ctx.set_max_expansions(800)
+    O.set_max_expansions(800)
+    runs = {}
+    try:
+        # a 256 x 256-cell grid with its separator column is budgeted at 10 x 8 blocks of 8 KiB:
+        # room for all grids / for three at a time / for one
+        for budget in (8 << 30, 3 * 80 * 8192, 8192):
+            ctx.set_heuristic_workspace(budget)
+            r = api.plan_batch(ctx, m, CONF, starts, goals, cap=2048, closed_cap=800)
+            runs[budget] = {k: np.array(r[k], copy=True) for k in ("status", "len", "cost", "x", "y", "yaw", "dir", "closed")}
+            runs[budget]["exp"] = np.array([int(s.expansions) for s in r["stats"]])
+            runs[budget]["poses"] = np.array([int(s.poses_checked) for s in r["stats"]])
+            if budget == 8192:
+                last = r
+        ref = runs[8 << 30]
+        assert (ref["status"] == 0).sum() >= 60 and ref["exp"].max() > 10
+        for budget, r in runs.items():
+            for k, v in ref.items():
+                assert np.array_equal(v, r[k], equal_nan=True), (budget, k)
+        om = O.OracleMap(ox, oy)
+        differ = 0
+        for i in range(0, len(starts), 8):
+            e = om.plan(CONF, starts[i], goals[i])
+            differ += not same_batch_query(last, int(i), e, 800)
+        assert differ <= 1, differ
+    finally:
+        ctx.set_heuristic_workspace(8 << 30)
+        ctx.set_max_expansions(100000)
+        O.set_max_expansions(0)

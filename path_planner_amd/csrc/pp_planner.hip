@@ -52,30 +52,30 @@ struct SNode {  // data_struct.rs:2-14 without the point lists (regenerated for 
 
 // calc_index key -> node slot, open addressing with linear probing.  The open and closed sets of
 // a query see a lookup per rollout (78 per closed node) and rarely hold more than a few hundred
-// keys; std::unordered_map spends most of that in its per-node allocations.
+// keys; std::unordered_map spends most of that in its per-node allocations.  Key and value share a
+// 16-byte slot, so a lookup that does not collide touches one cache line.
 class KeyMap {
  public:
   static constexpr int32_t kEmpty = -1, kGone = -2;
   bool empty() const { return live_ == 0; }
   void clear() {  // keeps the table
-    std::fill(val_.begin(), val_.end(), kEmpty);
+    for (Slot& s : tab_) s.val = kEmpty;
     used_ = live_ = 0;
   }
   int32_t* find(uint64_t key) {
     if (cap_ == 0) return nullptr;
     for (size_t i = hash(key) & (cap_ - 1);; i = (i + 1) & (cap_ - 1)) {
-      if (val_[i] == kEmpty) return nullptr;
-      if (val_[i] != kGone && key_[i] == key) return &val_[i];
+      Slot& s = tab_[i];
+      if (s.val == kEmpty) return nullptr;
+      if (s.val != kGone && s.key == key) return &s.val;
     }
   }
   bool contains(uint64_t key) { return find(key) != nullptr; }
-  // Asks for the cache lines a lookup of `key` starts at (a batch of thousands of queries finds
+  // Asks for the cache line a lookup of `key` starts at (a batch of thousands of queries finds
   // none of its tables in cache when its turn comes).
   void prefetch(uint64_t key) const {
     if (cap_ == 0) return;
-    const size_t i = hash(key) & (cap_ - 1);
-    __builtin_prefetch(&val_[i]);
-    __builtin_prefetch(&key_[i]);
+    __builtin_prefetch(&tab_[hash(key) & (cap_ - 1)]);
   }
   void set(uint64_t key, int32_t v) {  // insert or overwrite
     if (int32_t* p = find(key)) {
@@ -84,10 +84,10 @@ class KeyMap {
     }
     if ((used_ + 1) * 2 > cap_) grow();
     size_t i = hash(key) & (cap_ - 1);
-    while (val_[i] >= 0) i = (i + 1) & (cap_ - 1);
-    if (val_[i] == kEmpty) ++used_;
-    key_[i] = key;
-    val_[i] = v;
+    while (tab_[i].val >= 0) i = (i + 1) & (cap_ - 1);
+    if (tab_[i].val == kEmpty) ++used_;
+    tab_[i].key = key;
+    tab_[i].val = v;
     ++live_;
   }
   void erase(int32_t* slot) {
@@ -96,6 +96,11 @@ class KeyMap {
   }
 
  private:
+  struct Slot {
+    uint64_t key;
+    int32_t val;
+    int32_t pad_;
+  };
   static size_t hash(uint64_t k) {
     k ^= k >> 33;
     k *= 0xff51afd7ed558ccdull;
@@ -103,26 +108,22 @@ class KeyMap {
     return (size_t)k;
   }
   void grow() {
-    std::vector<uint64_t> ok;
-    std::vector<int32_t> ov;
-    ok.swap(key_);
-    ov.swap(val_);
+    std::vector<Slot> old;
+    old.swap(tab_);
     cap_ = std::max<size_t>(64, live_ * 4 > cap_ ? cap_ * 2 : cap_);  // tombstones alone do not double it
-    key_.assign(cap_, 0);
-    val_.assign(cap_, kEmpty);
+    tab_.assign(cap_, Slot{0, kEmpty, 0});
     used_ = live_ = 0;
-    for (size_t i = 0; i < ov.size(); ++i)
-      if (ov[i] >= 0) {
-        size_t j = hash(ok[i]) & (cap_ - 1);
-        while (val_[j] != kEmpty) j = (j + 1) & (cap_ - 1);
-        key_[j] = ok[i];
-        val_[j] = ov[i];
+    for (const Slot& o : old)
+      if (o.val >= 0) {
+        size_t j = hash(o.key) & (cap_ - 1);
+        while (tab_[j].val != kEmpty) j = (j + 1) & (cap_ - 1);
+        tab_[j].key = o.key;
+        tab_[j].val = o.val;
         ++used_;
         ++live_;
       }
   }
-  std::vector<uint64_t> key_;
-  std::vector<int32_t> val_;
+  std::vector<Slot> tab_;
   size_t cap_ = 0, used_ = 0, live_ = 0;  // used_ counts tombstones too
 };
 
@@ -135,6 +136,75 @@ struct HeapLess {  // BinaryHeap<(Reverse(f), key)>: top = min f, ties -> larges
     if (a.f != b.f) return a.f > b.f;
     return a.key < b.key;
   }
+};
+
+// The open list's priority queue (hybrid_astar.rs:150-160): pop order = HeapLess's top, a total
+// order on (f, key), so any heap gives the reference's sequence.  Four children per node, stored so
+// that the four share one 64-byte line: a pop on a heap that has left the cache (thousands of
+// queries take turns) walks half as many lines as a binary heap.
+class OpenHeap {
+ public:
+  OpenHeap() = default;
+  OpenHeap(const OpenHeap&) = delete;
+  OpenHeap& operator=(const OpenHeap&) = delete;
+  OpenHeap(OpenHeap&& o) noexcept : a_(o.a_), n_(o.n_), cap_(o.cap_) { o.a_ = nullptr, o.n_ = o.cap_ = 0; }
+  OpenHeap& operator=(OpenHeap&& o) noexcept {
+    if (this != &o) {
+      std::free(a_);
+      a_ = o.a_, n_ = o.n_, cap_ = o.cap_;
+      o.a_ = nullptr, o.n_ = o.cap_ = 0;
+    }
+    return *this;
+  }
+  ~OpenHeap() { std::free(a_); }
+  void clear() { n_ = 0; }  // keeps the storage
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  const HeapEnt& operator[](size_t i) const { return a_[i + kPad]; }  // i < size(), heap order
+  void push(HeapEnt e) {
+    if (n_ + kPad >= cap_) grow();
+    size_t i = n_++;
+    while (i > 0) {
+      const size_t p = (i - 1) / 4;
+      if (!before(e, at(p))) break;
+      at(i) = at(p);
+      i = p;
+    }
+    at(i) = e;
+  }
+  HeapEnt pop() {  // size() > 0
+    const HeapEnt top = at(0), e = at(--n_);
+    size_t i = 0;
+    for (;;) {
+      const size_t c0 = 4 * i + 1;
+      if (c0 >= n_) break;
+      size_t m = c0;
+      const size_t ce = std::min(c0 + 4, n_);
+      for (size_t c = c0 + 1; c < ce; ++c)
+        if (before(at(c), at(m))) m = c;
+      if (!before(at(m), e)) break;
+      at(i) = at(m);
+      i = m;
+    }
+    if (n_) at(i) = e;
+    return top;
+  }
+
+ private:
+  static constexpr size_t kPad = 3;  // entry k sits in slot k + 3: the children 4i+1 .. 4i+4 fill line i + 1
+  static bool before(const HeapEnt& a, const HeapEnt& b) { return a.f < b.f || (a.f == b.f && a.key > b.key); }
+  HeapEnt& at(size_t i) { return a_[i + kPad]; }
+  void grow() {
+    const size_t cap = cap_ ? cap_ * 2 : 256;
+    HeapEnt* a = (HeapEnt*)std::aligned_alloc(64, cap * sizeof(HeapEnt));
+    if (!a) throw std::bad_alloc();
+    if (a_) std::memcpy((void*)a, (const void*)a_, (n_ + kPad) * sizeof(HeapEnt));
+    std::free(a_);
+    a_ = a;
+    cap_ = cap;
+  }
+  HeapEnt* a_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
 };
 
 // What the device returns for one node: the analytic shot from its end pose and its P primitive
@@ -163,7 +233,7 @@ struct Query {
   int32_t hmap_slot = -1;
   std::vector<SNode> nodes;
   KeyMap open, closed;
-  std::vector<HeapEnt> heap;  // std::push_heap / pop_heap under HeapLess
+  OpenHeap heap;
   std::unordered_map<int32_t, Expansion> cache;  // expansions fetched ahead of their node's turn
   std::vector<int32_t> want;                     // nodes to expand in this round, want[0] = curr
   size_t item0 = 0;                              // this query's first item in the round's batch
@@ -537,7 +607,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       uint64_t key = calc_index(n.xind, n.yind, n.yawind, P);
       q.nodes.push_back(n);
       q.open.set(key, 0);
-      q.heap.push_back({f, key});
+      q.heap.push({f, key});
     }
   }
 
@@ -670,6 +740,11 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
           q.closed.prefetch(ckey[i]);
           q.open.prefetch(ckey[i]);
         }
+    // a child whose key is open is compared with the open node's cost: that node's line as well
+    if (keyed)
+      for (uint32_t i = 0; i < NP; ++i)
+        if (v.valid[i] & 1u)
+          if (const int32_t* it = q.open.find(ckey[i])) __builtin_prefetch(&q.nodes[*it].cost);
     for (uint32_t i = 0; i < NP; ++i) {
       ++q.st.rollouts;
       const uint8_t vf = v.valid[i];
@@ -707,8 +782,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       n.prim = (int32_t)i;
       q.nodes.push_back(n);
       const int32_t id = (int32_t)q.nodes.size() - 1;
-      q.heap.push_back({f, key});
-      std::push_heap(q.heap.begin(), q.heap.end(), HeapLess());
+      q.heap.push({f, key});
       if (!it)
         q.open.set(key, id);
       else
@@ -744,9 +818,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         return;
       }
       while (!q.open.empty()) {
-        std::pop_heap(q.heap.begin(), q.heap.end(), HeapLess());
-        const HeapEnt e = q.heap.back();
-        q.heap.pop_back();
+        const HeapEnt e = q.heap.pop();
         int32_t* it = q.open.find(e.key);
         if (!it) {
           ++q.st.stale_pops;

@@ -50,57 +50,55 @@ struct SNode {  // data_struct.rs:2-14 without the point lists (regenerated for 
   int32_t prim;      // primitive index that produced it
 };
 
-// calc_index key -> node slot, open addressing with linear probing.  The open and closed sets of
-// a query see a lookup per rollout (78 per closed node) and rarely hold more than a few hundred
-// keys; std::unordered_map spends most of that in its per-node allocations.  Key and value share a
-// 16-byte slot, so a lookup that does not collide touches one cache line.
-class KeyMap {
+// calc_index key -> the query's node of that cell, for the open and the closed set alike
+// (hybrid_astar.rs:147-149 keeps two hash maps).  A rollout is looked up once: closed -> dropped
+// (:187), open -> kept only if cheaper than the open node (:199), whose cost sits in the slot so the
+// node itself is not touched.  Closing a node (:161-175) flips its slot in place, so nothing is
+// ever erased.  Open addressing with linear probing over 32-byte slots, two to a cache line.
+class NodeTable {
  public:
-  static constexpr int32_t kEmpty = -1, kGone = -2;
-  bool empty() const { return live_ == 0; }
+  enum : int32_t { kEmpty = 0, kOpen = 1, kClosed = 2 };
+  struct Slot {
+    uint64_t key;
+    double cost;    // of the open node
+    int32_t node;   // its index in the query's node store
+    int32_t state;
+  };
   void clear() {  // keeps the table
-    for (Slot& s : tab_) s.val = kEmpty;
-    used_ = live_ = 0;
+    for (Slot& s : tab_) s.state = kEmpty;
+    used_ = open_ = 0;
   }
-  int32_t* find(uint64_t key) {
+  size_t open_count() const { return open_; }
+  Slot* find(uint64_t key) {
     if (cap_ == 0) return nullptr;
     for (size_t i = hash(key) & (cap_ - 1);; i = (i + 1) & (cap_ - 1)) {
       Slot& s = tab_[i];
-      if (s.val == kEmpty) return nullptr;
-      if (s.val != kGone && s.key == key) return &s.val;
+      if (s.state == kEmpty) return nullptr;
+      if (s.key == key) return &s;
     }
   }
-  bool contains(uint64_t key) { return find(key) != nullptr; }
   // Asks for the cache line a lookup of `key` starts at (a batch of thousands of queries finds
   // none of its tables in cache when its turn comes).
   void prefetch(uint64_t key) const {
     if (cap_ == 0) return;
     __builtin_prefetch(&tab_[hash(key) & (cap_ - 1)]);
   }
-  void set(uint64_t key, int32_t v) {  // insert or overwrite
-    if (int32_t* p = find(key)) {
-      *p = v;
-      return;
-    }
+  // A key that is not in the table enters the open set.  May move the table: slots found earlier
+  // are no longer valid.
+  void insert_open(uint64_t key, int32_t node, double cost) {
     if ((used_ + 1) * 2 > cap_) grow();
     size_t i = hash(key) & (cap_ - 1);
-    while (tab_[i].val >= 0) i = (i + 1) & (cap_ - 1);
-    if (tab_[i].val == kEmpty) ++used_;
-    tab_[i].key = key;
-    tab_[i].val = v;
-    ++live_;
+    while (tab_[i].state != kEmpty) i = (i + 1) & (cap_ - 1);
+    tab_[i] = Slot{key, cost, node, kOpen};
+    ++used_;
+    ++open_;
   }
-  void erase(int32_t* slot) {
-    *slot = kGone;
-    --live_;
+  void close(Slot* s) {
+    s->state = kClosed;
+    --open_;
   }
 
  private:
-  struct Slot {
-    uint64_t key;
-    int32_t val;
-    int32_t pad_;
-  };
   static size_t hash(uint64_t k) {
     k ^= k >> 33;
     k *= 0xff51afd7ed558ccdull;
@@ -110,21 +108,17 @@ class KeyMap {
   void grow() {
     std::vector<Slot> old;
     old.swap(tab_);
-    cap_ = std::max<size_t>(64, live_ * 4 > cap_ ? cap_ * 2 : cap_);  // tombstones alone do not double it
-    tab_.assign(cap_, Slot{0, kEmpty, 0});
-    used_ = live_ = 0;
+    cap_ = std::max<size_t>(64, cap_ * 2);
+    tab_.assign(cap_, Slot{0, 0.0, 0, kEmpty});
     for (const Slot& o : old)
-      if (o.val >= 0) {
+      if (o.state != kEmpty) {
         size_t j = hash(o.key) & (cap_ - 1);
-        while (tab_[j].val != kEmpty) j = (j + 1) & (cap_ - 1);
-        tab_[j].key = o.key;
-        tab_[j].val = o.val;
-        ++used_;
-        ++live_;
+        while (tab_[j].state != kEmpty) j = (j + 1) & (cap_ - 1);
+        tab_[j] = o;
       }
   }
   std::vector<Slot> tab_;
-  size_t cap_ = 0, used_ = 0, live_ = 0;  // used_ counts tombstones too
+  size_t cap_ = 0, used_ = 0, open_ = 0;
 };
 
 struct HeapEnt {
@@ -232,7 +226,7 @@ struct Query {
   double start[3], goal[3];
   int32_t hmap_slot = -1;
   std::vector<SNode> nodes;
-  KeyMap open, closed;
+  NodeTable tab;  // open and closed set
   OpenHeap heap;
   std::unordered_map<int32_t, Expansion> cache;  // expansions fetched ahead of their node's turn
   std::vector<int32_t> want;                     // nodes to expand in this round, want[0] = curr
@@ -250,8 +244,7 @@ struct Query {
   void reset() {
     hmap_slot = -1;
     nodes.clear();
-    open.clear();
-    closed.clear();
+    tab.clear();
     heap.clear();
     cache.clear();
     want.clear();
@@ -606,7 +599,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       }
       uint64_t key = calc_index(n.xind, n.yind, n.yawind, P);
       q.nodes.push_back(n);
-      q.open.set(key, 0);
+      q.tab.insert_open(key, 0, n.cost);
       q.heap.push({f, key});
     }
   }
@@ -737,14 +730,8 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       for (uint32_t i = 0; i < NP; ++i)
         if (v.valid[i] & 1u) {
           ckey[i] = calc_index(v.xind[i], v.yind[i], v.yawind[i], P);
-          q.closed.prefetch(ckey[i]);
-          q.open.prefetch(ckey[i]);
+          q.tab.prefetch(ckey[i]);
         }
-    // a child whose key is open is compared with the open node's cost: that node's line as well
-    if (keyed)
-      for (uint32_t i = 0; i < NP; ++i)
-        if (v.valid[i] & 1u)
-          if (const int32_t* it = q.open.find(ckey[i])) __builtin_prefetch(&q.nodes[*it].cost);
     for (uint32_t i = 0; i < NP; ++i) {
       ++q.st.rollouts;
       const uint8_t vf = v.valid[i];
@@ -757,10 +744,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       }
       if (!(vf & 1u)) continue;
       const uint64_t key = keyed ? ckey[i] : calc_index(v.xind[i], v.yind[i], v.yawind[i], P);
-      if (q.closed.contains(key)) continue;
       const double cost = v.cost[i];
-      int32_t* it = q.open.find(key);
-      if (it && !(q.nodes[*it].cost > cost)) continue;
+      NodeTable::Slot* sl = q.tab.find(key);
+      if (sl && (sl->state == NodeTable::kClosed || !(sl->cost > cost))) continue;
       const double f = v.f[i];
       if (f != f) {  // NotNan::new(..).unwrap()
         q.status = PP_ERR_NAN_COST;
@@ -783,10 +769,12 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       q.nodes.push_back(n);
       const int32_t id = (int32_t)q.nodes.size() - 1;
       q.heap.push({f, key});
-      if (!it)
-        q.open.set(key, id);
-      else
-        *it = id;
+      if (!sl) {
+        q.tab.insert_open(key, id, cost);
+      } else {
+        sl->node = id;
+        sl->cost = cost;
+      }
     }
   };
   auto view_of = [&](const Expansion& e) {
@@ -817,17 +805,16 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         q.status = PP_ERR_LIMIT;
         return;
       }
-      while (!q.open.empty()) {
+      while (q.tab.open_count() != 0) {
         const HeapEnt e = q.heap.pop();
-        int32_t* it = q.open.find(e.key);
-        if (!it) {
+        NodeTable::Slot* sl = q.tab.find(e.key);
+        if (!sl || sl->state != NodeTable::kOpen) {
           ++q.st.stale_pops;
           continue;
         }
-        q.curr = *it;
+        q.curr = sl->node;
         q.curr_key = e.key;
-        q.open.erase(it);
-        q.closed.set(e.key, q.curr);
+        q.tab.close(sl);
         if (q.st.closed_order && q.st.expansions < q.st.closed_cap) q.st.closed_order[q.st.expansions] = e.key;
         ++q.st.expansions;
         break;
@@ -849,9 +836,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     size_t nc = 0;
     const size_t scan = std::min<size_t>(q.heap.size(), 31);
     for (size_t k = 0; k < scan; ++k) {
-      int32_t* it = q.open.find(q.heap[k].key);
-      if (!it) continue;
-      const int32_t id = *it;
+      const NodeTable::Slot* sl = q.tab.find(q.heap[k].key);
+      if (!sl || sl->state != NodeTable::kOpen) continue;
+      const int32_t id = sl->node;
       bool dup = q.cache.count(id) != 0;
       for (size_t j = 0; j < nc && !dup; ++j) dup = cand[j].id == id;  // a key's older entries name the same node
       if (!dup) cand[nc++] = Cand{q.heap[k], id};

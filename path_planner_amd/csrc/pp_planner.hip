@@ -1062,6 +1062,16 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         e.words.resize(8 * (size_t)NP);
         for (int a = 0; a < 8; ++a) std::memcpy(e.words.data() + (size_t)a * NP, v_arr[a] + it * NP * 8, (size_t)NP * 8);
       }
+      // the next query's results (written by the device: in no cache) and the query itself
+      if (depth == 1 && k + 1 < ln.nl) {
+        const size_t nb = (k + 1) * NP;
+        __builtin_prefetch(&shot[k + 1]);
+        for (size_t o = 0; o < NP; o += 64) __builtin_prefetch(v_valid + nb + o);
+        for (int a = 0; a < 8; ++a)
+          for (size_t o = 0; o < (size_t)NP * 8; o += 64) __builtin_prefetch(v_arr[a] + nb * 8 + o);
+        const char* qn = (const char*)&Q[ln.ids[k + 1]];
+        for (size_t o = 0; o < sizeof(Query); o += 64) __builtin_prefetch(qn + o);
+      }
       const size_t it = first, b = it * NP;
       const ExpansionView v{&shot[it], v_valid + b, (const uint64_t*)v_arr[0] + b, (const uint64_t*)v_arr[1] + b,
                             (const int64_t*)v_arr[2] + b, (const double*)v_arr[3] + b, (const double*)v_arr[4] + b,

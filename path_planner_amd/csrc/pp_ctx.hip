@@ -59,6 +59,7 @@ extern "C" void pp_ctx_destroy(pp_ctx* ctx) {
   if (ctx->wave_buf) (void)hipFree(ctx->wave_buf);
   if (ctx->wave_counts) (void)hipHostFree(ctx->wave_counts);
   if (ctx->wave_event) (void)hipEventDestroy(ctx->wave_event);
+  if (ctx->ftab_buf) (void)hipFree(ctx->ftab_buf);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->plan_buf) (void)hipFree(ctx->plan_buf);
   if (ctx->hmap_buf) (void)hipFree(ctx->hmap_buf);

@@ -44,7 +44,35 @@ struct PpExpandDev {
   // optional: entries of primitives that are not valid keep whatever the arrays held (only the
   // valid byte is written) -- for outputs that cross PCIe
   int32_t sparse = 0;
+  // optional: per-query tables of the cells a search has already closed or holds open (key =
+  // calc_index, hybrid_astar.rs:516-520; value = bit pattern of the open node's cost, 0 for a closed
+  // cell; costs are non-negative, so the patterns order like the costs).  A valid node whose key is
+  // in its query's table with a value not above its own cost is one the search drops
+  // (hybrid_astar.rs:187, :199): it loses bit 0 of its valid byte and gets bit 5 instead.  The
+  // tables may lag behind the search -- a cell is never re-opened and an open cost only falls, so an
+  // old entry still rules out nothing the search would keep.
+  const unsigned long long* ftab = nullptr;  // table q: ftab_slots (key, value) pairs from ftab + q * 2 * ftab_slots
+  const int32_t* ftab_id = nullptr;          // per parent: its query's table, -1 = none
+  uint64_t ftab_slots = 0;                   // a power of two
+  int64_t f_minyaw = 0;                      // calc_index: Param.minyaw, xw, yw (minx, miny are in the launch parameters)
+  uint64_t f_xw = 0, f_yw = 0;
 };
+
+// The tables above: open addressing, linear probing, at most kFtabProbes slots looked at (an entry
+// that finds no room within them is simply not recorded).
+constexpr int kFtabProbes = 16;
+constexpr unsigned long long kFtabEmpty = ~0ull;
+__host__ __device__ inline uint64_t pp_ftab_hash(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  return k;
+}
+struct PpFtabUpd {   // "cell `key` of table `tab` is now open at cost bits `value`" (0: closed)
+  unsigned long long key, value;
+  int32_t tab, pad_;
+};
+void pp_ftab_update_launch(pp_ctx* ctx, uint32_t n, const PpFtabUpd* upd, unsigned long long* ftab, uint64_t slots);
 
 struct PpExpandPlan {
   uint32_t n_prim = 0;

@@ -94,9 +94,31 @@ __device__ __forceinline__ void pp_expand_item(uint64_t t, uint32_t n_prim, cons
   cost += prm.steer_change_cost * fabs(psteer[p] - u);
   cost += pcost[p];
 
+  // a node the search is known to drop: its cell is closed, or open at no higher cost
+  bool known = false;
+  if (valid && out.ftab) {
+    const int32_t tq = out.ftab_id[p];
+    if (tq >= 0) {
+      const unsigned long long key = (unsigned long long)(yawind - out.f_minyaw) * out.f_xw * out.f_yw +
+                                     (yind - prm.miny) * out.f_xw + (xind - prm.minx);
+      const unsigned long long cb = (unsigned long long)__double_as_longlong(cost);
+      const unsigned long long* tab = out.ftab + (uint64_t)tq * 2 * out.ftab_slots;
+      uint64_t i = pp_ftab_hash(key) & (out.ftab_slots - 1);
+      for (int probe = 0; probe < kFtabProbes; ++probe) {
+        const ulonglong2 e = *(const ulonglong2*)(tab + 2 * i);
+        if (e.x == key) {
+          known = e.y <= cb;
+          break;
+        }
+        if (e.x == kFtabEmpty) break;
+        i = (i + 1) & (out.ftab_slots - 1);
+      }
+    }
+  }
+  if (known) valid = false;
   // bit3: the index test passed, i.e. the primitive's poses were handed to is_collision
   unsigned v = (valid ? 1u : 0u) | (amb ? 2u : 0u) | ((fl & PP_F_NONFINITE) ? 4u : 0u) |
-               (in_bounds ? 8u : 0u);
+               (in_bounds ? 8u : 0u) | (known ? 32u : 0u);
   if (out.fcost) {
     double fc = 0.0;
     if (valid) {

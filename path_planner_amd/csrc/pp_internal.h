@@ -82,6 +82,8 @@ struct pp_ctx {
   uint64_t wave_stats[4] = {0, 0, 0, 0};  // last relaxation: rounds, tile visits, sweep pairs, tiles
   uint32_t* wave_counts = nullptr;  // pinned: the round counters as last read back
   hipEvent_t wave_event = nullptr;  // that read-back
+  void* ftab_buf = nullptr;  // the planner's per-query tables of known cells (pp_expand.h)
+  size_t ftab_bytes = 0;
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   // the planner's per-round device staging (grown on demand, never shrunk)

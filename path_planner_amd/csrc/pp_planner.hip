@@ -57,23 +57,33 @@ struct SNode {  // data_struct.rs:2-14 without the point lists (regenerated for 
 // ever erased.  Open addressing with linear probing over 32-byte slots, two to a cache line.
 class NodeTable {
  public:
-  enum : int32_t { kEmpty = 0, kOpen = 1, kClosed = 2 };
+  enum : int32_t { kOpen = 1, kClosed = 2 };
   struct Slot {
     uint64_t key;
     double cost;    // of the open node
     int32_t node;   // its index in the query's node store
-    int32_t state;
+    uint32_t tag;   // 4 * generation + kOpen / kClosed; a slot of another generation is empty
+    int32_t state() const { return (int32_t)(tag & 3u); }
   };
-  void clear() {  // keeps the table
-    for (Slot& s : tab_) s.state = kEmpty;
+  void clear() {  // keeps the table: its slots become empty by belonging to an older generation
+    if (++gen_ == (1u << 30)) {
+      for (Slot& s : tab_) s.tag = 0;
+      gen_ = 1;
+    }
     used_ = open_ = 0;
   }
   size_t open_count() const { return open_; }
+  size_t size() const { return used_; }  // open and closed
+  template <class F>
+  void for_each(F&& f) const {
+    for (const Slot& s : tab_)
+      if (live(s)) f(s);
+  }
   Slot* find(uint64_t key) {
     if (cap_ == 0) return nullptr;
     for (size_t i = hash(key) & (cap_ - 1);; i = (i + 1) & (cap_ - 1)) {
       Slot& s = tab_[i];
-      if (s.state == kEmpty) return nullptr;
+      if (!live(s)) return nullptr;
       if (s.key == key) return &s;
     }
   }
@@ -88,17 +98,18 @@ class NodeTable {
   void insert_open(uint64_t key, int32_t node, double cost) {
     if ((used_ + 1) * 2 > cap_) grow();
     size_t i = hash(key) & (cap_ - 1);
-    while (tab_[i].state != kEmpty) i = (i + 1) & (cap_ - 1);
-    tab_[i] = Slot{key, cost, node, kOpen};
+    while (live(tab_[i])) i = (i + 1) & (cap_ - 1);
+    tab_[i] = Slot{key, cost, node, gen_ * 4u + (uint32_t)kOpen};
     ++used_;
     ++open_;
   }
   void close(Slot* s) {
-    s->state = kClosed;
+    s->tag = gen_ * 4u + (uint32_t)kClosed;
     --open_;
   }
 
  private:
+  bool live(const Slot& s) const { return (s.tag >> 2) == gen_; }
   static size_t hash(uint64_t k) {
     k ^= k >> 33;
     k *= 0xff51afd7ed558ccdull;
@@ -109,16 +120,17 @@ class NodeTable {
     std::vector<Slot> old;
     old.swap(tab_);
     cap_ = std::max<size_t>(64, cap_ * 2);
-    tab_.assign(cap_, Slot{0, 0.0, 0, kEmpty});
+    tab_.assign(cap_, Slot{0, 0.0, 0, 0u});
     for (const Slot& o : old)
-      if (o.state != kEmpty) {
+      if (live(o)) {
         size_t j = hash(o.key) & (cap_ - 1);
-        while (tab_[j].state != kEmpty) j = (j + 1) & (cap_ - 1);
+        while (live(tab_[j])) j = (j + 1) & (cap_ - 1);
         tab_[j] = o;
       }
   }
   std::vector<Slot> tab_;
   size_t cap_ = 0, used_ = 0, open_ = 0;
+  uint32_t gen_ = 1;
 };
 
 struct HeapEnt {
@@ -166,12 +178,25 @@ class OpenHeap {
     }
     at(i) = e;
   }
+  // The lines a pop and the pushes after it start with: the first three levels and the last entry
+  // with its parent (asked for when a query's turn begins, used a few hundred cycles later).
+  void prefetch_ends() const {
+    if (!a_) return;
+    for (size_t o = 0; o < 24 && o < n_ + kPad; o += 4) __builtin_prefetch(a_ + o);
+    __builtin_prefetch(a_ + n_ + kPad);
+    if (n_) __builtin_prefetch(a_ + (n_ - 1) / 4 + kPad);
+  }
   HeapEnt pop() {  // size() > 0
     const HeapEnt top = at(0), e = at(--n_);
     size_t i = 0;
     for (;;) {
       const size_t c0 = 4 * i + 1;
       if (c0 >= n_) break;
+      // the sixteen grandchildren are contiguous (four lines): whichever child wins, its children
+      // are on their way while the four children are compared
+      const size_t g0 = 4 * c0 + 1;
+      if (g0 < n_)
+        for (size_t o = 0; o < 16; o += 4) __builtin_prefetch(a_ + g0 + kPad + o);
       size_t m = c0;
       const size_t ce = std::min(c0 + 4, n_);
       for (size_t c = c0 + 1; c < ce; ++c)
@@ -233,6 +258,8 @@ struct Query {
   size_t item0 = 0;                              // this query's first item in the round's batch
   int32_t status = PP_OK;
   bool live = false;
+  int32_t ftab = -1;               // the query's table of known cells on the device (pp_expand.h), -1 = none
+  std::vector<PpFtabUpd> upd;      // what that table has not been told yet
   int32_t curr = -1;       // node closed last and not yet expanded
   uint64_t curr_key = 0;
   // outcome
@@ -251,6 +278,8 @@ struct Query {
     item0 = 0;
     status = PP_OK;
     live = false;
+    ftab = -1;
+    upd.clear();
     curr = -1;
     curr_key = 0;
     found = false;
@@ -635,9 +664,12 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   // per-round inputs (start pose + goal pose, pdir, psteer, pcost, hmap_id) and outputs share one
   // device buffer and one pinned mirror, laid out per round; the motion table and the
   // Reeds-Shepp work arrays sit behind them
-  const size_t io_lane = al256(6 * Bl * 8) + 3 * al256(Bl * 8) + al256(Bl * 4) + al256(Bl * sizeof(PpShotOut)) +
+  const size_t io_lane = al256(6 * Bl * 8) + 3 * al256(Bl * 8) + 2 * al256(Bl * 4) + al256(Bl * sizeof(PpShotOut)) +
                          al256(items) + 8 * al256(items * 8);
   const size_t io_bytes = (two_lanes ? 2 : 1) * io_lane;
+  // pinned only, behind the mirror: per lane, the news of a round for the tables of known cells
+  const size_t upd_cap = Bl * (NP + 2);
+  const size_t upd_lane = al256(upd_cap * sizeof(PpFtabUpd));
   off = io_bytes;
   const size_t o_mot = take(plan.motion.size() * 8);
   const size_t o_cand = take(B * PP_RS_MAX_PATHS * sizeof(PpRsCand)), o_pair = take(B * sizeof(PpRsPair));
@@ -649,7 +681,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     PP_HIP(ctx, hipMalloc(&ctx->plan_buf, off));
     ctx->plan_bytes = off;
   }
-  st = pp_pinned_reserve(ctx, io_bytes);
+  st = pp_pinned_reserve(ctx, io_bytes + 2 * upd_lane);
   if (st != PP_OK) return st;
   char* d = (char*)ctx->plan_buf;
   char* h = (char*)ctx->pinned;
@@ -693,8 +725,13 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     double x, y, yaw, gx, gy, gyaw;
     int64_t dir;
     double steer, cost;
-    int32_t hid;
+    int32_t hid, fid;
     uint8_t alive;
+  };
+  auto f64_bits = [](double v) {
+    unsigned long long b;
+    std::memcpy(&b, &v, 8);
+    return b;
   };
 
   // ---- lock-step rounds
@@ -723,6 +760,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       q.live = false;
       return;
     }
+    // where the pushes will write and the pop after them will start
+    q.heap.prefetch_ends();
+    __builtin_prefetch(q.nodes.data() + q.nodes.size());
     // keys of the valid children first, with their table lines requested, then the lookups
     uint64_t ckey[256];
     const bool keyed = NP <= 256;
@@ -746,7 +786,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       const uint64_t key = keyed ? ckey[i] : calc_index(v.xind[i], v.yind[i], v.yawind[i], P);
       const double cost = v.cost[i];
       NodeTable::Slot* sl = q.tab.find(key);
-      if (sl && (sl->state == NodeTable::kClosed || !(sl->cost > cost))) continue;
+      if (sl && (sl->state() == NodeTable::kClosed || !(sl->cost > cost))) continue;
       const double f = v.f[i];
       if (f != f) {  // NotNan::new(..).unwrap()
         q.status = PP_ERR_NAN_COST;
@@ -775,6 +815,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         sl->node = id;
         sl->cost = cost;
       }
+      if (q.ftab >= 0) q.upd.push_back(PpFtabUpd{key, f64_bits(cost), q.ftab, 0});
     }
   };
   auto view_of = [&](const Expansion& e) {
@@ -808,13 +849,14 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       while (q.tab.open_count() != 0) {
         const HeapEnt e = q.heap.pop();
         NodeTable::Slot* sl = q.tab.find(e.key);
-        if (!sl || sl->state != NodeTable::kOpen) {
+        if (!sl || sl->state() != NodeTable::kOpen) {
           ++q.st.stale_pops;
           continue;
         }
         q.curr = sl->node;
         q.curr_key = e.key;
         q.tab.close(sl);
+        if (q.ftab >= 0) q.upd.push_back(PpFtabUpd{e.key, 0ull, q.ftab, 0});
         if (q.st.closed_order && q.st.expansions < q.st.closed_cap) q.st.closed_order[q.st.expansions] = e.key;
         ++q.st.expansions;
         break;
@@ -826,25 +868,26 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       }
     }
   };
-  // Open nodes likely to be closed soon: the best entries among the first levels of the heap.
+  // Open nodes likely to be closed soon: the entries the next pops return if nothing cheaper is
+  // pushed meanwhile, found by walking the heap down from its root (the best entry not yet taken is
+  // always a child of one that was).
   auto speculate = [&](Query& q, size_t depth) {
-    struct Cand {
-      HeapEnt e;
-      int32_t id;
-    };
-    Cand cand[32];
-    size_t nc = 0;
-    const size_t scan = std::min<size_t>(q.heap.size(), 31);
-    for (size_t k = 0; k < scan; ++k) {
-      const NodeTable::Slot* sl = q.tab.find(q.heap[k].key);
-      if (!sl || sl->state != NodeTable::kOpen) continue;
+    size_t frontier[132], nf = 0;
+    if (q.heap.size()) frontier[nf++] = 0;
+    for (int step = 0; step < 32 && nf && q.want.size() < depth; ++step) {
+      size_t b = 0;
+      for (size_t j = 1; j < nf; ++j)
+        if (HeapLess()(q.heap[frontier[b]], q.heap[frontier[j]])) b = j;
+      const size_t i = frontier[b];
+      frontier[b] = frontier[--nf];
+      for (size_t c = 4 * i + 1; c <= 4 * i + 4 && c < q.heap.size(); ++c) frontier[nf++] = c;
+      const NodeTable::Slot* sl = q.tab.find(q.heap[i].key);
+      if (!sl || sl->state() != NodeTable::kOpen) continue;  // a stale entry
       const int32_t id = sl->node;
       bool dup = q.cache.count(id) != 0;
-      for (size_t j = 0; j < nc && !dup; ++j) dup = cand[j].id == id;  // a key's older entries name the same node
-      if (!dup) cand[nc++] = Cand{q.heap[k], id};
+      for (size_t j = 1; j < q.want.size() && !dup; ++j) dup = q.want[j] == id;  // a key's older entries name the same node
+      if (!dup) q.want.push_back(id);
     }
-    std::sort(cand, cand + nc, [](const Cand& a, const Cand& b) { return HeapLess()(b.e, a.e); });
-    for (size_t k = 0; k < nc && q.want.size() < depth; ++k) q.want.push_back(cand[k].id);
   };
 
   const bool prof = getenv("PP_PLAN_PROFILE") != nullptr;
@@ -865,6 +908,11 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     int pc = 0;
     size_t nl = 0, ni = 0, depth = 1;
     size_t r_shot = 0, r_valid = 0, r_arr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // news for the tables of known cells, written by the workers as they apply a round
+    PpFtabUpd* upd = nullptr;
+    std::atomic<uint32_t> upd_n{0}, upd_fail{UINT32_MAX};  // records reserved; lowest reservation that did not fit
+    uint32_t rounds = 0;
+    bool unassigned = true;  // some live query may still be without a table
   };
   const size_t nlanes = two_lanes ? 2 : 1;
   Lane lanes[2];
@@ -872,6 +920,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     lanes[l].io_base = l * io_lane;
     lanes[l].item_base = l * Bl;
     lanes[l].done = state.lane_done[l];
+    lanes[l].upd = (PpFtabUpd*)(h + io_bytes + l * upd_lane);
   }
   for (uint64_t i = 0, k = 0; i < nq; ++i)
     if (Q[i].live) lanes[k++ % nlanes].ids.push_back((uint32_t)i);
@@ -884,6 +933,17 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   auto advance_emit = [&](Lane& ln, size_t k) {
     Query& q = Q[ln.ids[k]];
     advance(q);
+    if (const size_t nu = q.upd.size()) {
+      const uint32_t at = ln.upd_n.fetch_add((uint32_t)nu, std::memory_order_relaxed);
+      if (at + nu <= upd_cap) {
+        std::memcpy((void*)(ln.upd + at), q.upd.data(), nu * sizeof(PpFtabUpd));
+      } else {  // no room (a query ran through many expansions it had in its cache): the tables miss this news
+        uint32_t lo = ln.upd_fail.load(std::memory_order_relaxed);
+        while (at < lo && !ln.upd_fail.compare_exchange_weak(lo, at, std::memory_order_relaxed)) {
+        }
+      }
+      q.upd.clear();
+    }
     q.want.clear();
     q.want.push_back(q.curr);
     Emit& e = ln.emit[k];
@@ -900,6 +960,88 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     e.steer = n.steer;
     e.cost = n.cost;
     e.hid = q.hmap_slot;
+    e.fid = q.ftab;
+  };
+
+  // Tables of known cells (pp_expand.h).  A search that is still running after kFtabStartRound
+  // rounds gets a table on the device, filled with what it has closed and holds open so far and
+  // kept up to date round by round; from then on the device drops the rollouts the search would
+  // drop anyway, which is most of them (on the search-heavy benchmark 82 % of the valid ones), and
+  // the host never looks at them.  Short searches -- most of a typical batch -- never pay for it.
+  constexpr uint32_t kFtabStartRound = 64;
+  constexpr size_t kFtabMinLive = 64;
+  constexpr size_t kFtabBudget = (size_t)16 << 30;  // bytes of device memory for all tables
+  // the cost bit patterns order like the costs only if no cost term can be negative
+  bool ftab_off = !(plan.prm.backward_cost >= 0.0 && plan.prm.gear_cost >= 0.0 &&
+                    plan.prm.steer_angle_cost >= 0.0 && plan.prm.steer_change_cost >= 0.0);
+  uint64_t ftab_slots = 0;
+  uint32_t ftab_tables = 0, ftab_next = 0;
+  auto send_updates = [&](Lane& ln, bool send) {
+    const uint32_t n = std::min(ln.upd_n.load(std::memory_order_relaxed), ln.upd_fail.load(std::memory_order_relaxed));
+    if (n && send) pp_ftab_update_launch(ctx, n, ln.upd, (unsigned long long*)ctx->ftab_buf, ftab_slots);
+    ln.upd_n.store(0, std::memory_order_relaxed);
+    ln.upd_fail.store(UINT32_MAX, std::memory_order_relaxed);
+  };
+  auto ftab_assign = [&](Lane& ln) -> int32_t {
+    ln.unassigned = false;
+    if (ftab_slots == 0) {  // first time: tables for every query still alive
+      size_t live = 0;
+      for (size_t l = 0; l < nlanes; ++l) live += lanes[l].ids.size();
+      uint64_t slots = (uint64_t)1 << 17;
+      while (slots >= 4096 && live * slots * 16 > kFtabBudget) slots >>= 1;
+      if (slots < 4096 || live == 0) {
+        ftab_off = true;
+        return PP_OK;
+      }
+      const size_t need = live * slots * 16;
+      if (need > ctx->ftab_bytes) {
+        PP_HIP(ctx, hipStreamSynchronize(s));
+        if (ctx->ftab_buf) PP_HIP(ctx, hipFree(ctx->ftab_buf));
+        ctx->ftab_buf = nullptr;
+        ctx->ftab_bytes = 0;
+        PP_HIP(ctx, hipMalloc(&ctx->ftab_buf, need));
+        ctx->ftab_bytes = need;
+      }
+      PP_HIP(ctx, hipMemsetAsync(ctx->ftab_buf, 0xFF, need, s));  // empty keys, values above every cost
+      ftab_slots = slots;
+      ftab_tables = (uint32_t)live;
+      eo.ftab_slots = slots;
+      eo.f_minyaw = P.minyaw;
+      eo.f_xw = P.xw;
+      eo.f_yw = P.yw;
+    }
+    std::vector<uint32_t> fresh;
+    std::vector<size_t> base;
+    size_t total = 0;
+    for (size_t k = 0; k < ln.ids.size(); ++k) {
+      Query& q = Q[ln.ids[k]];
+      if (q.ftab >= 0 || ftab_next >= ftab_tables) continue;
+      q.ftab = (int32_t)ftab_next++;
+      ln.emit[k].fid = q.ftab;
+      fresh.push_back(ln.ids[k]);
+      base.push_back(total);
+      total += q.tab.size();
+    }
+    if (total == 0) return PP_OK;
+    if (total > UINT32_MAX) return PP_ERR_UNSUPPORTED;
+    std::vector<PpFtabUpd> all(total);
+    pool.run(fresh.size(), [&](size_t j) {
+      const Query& q = Q[fresh[j]];
+      PpFtabUpd* o = all.data() + base[j];
+      q.tab.for_each([&](const NodeTable::Slot& sl) {
+        *o++ = PpFtabUpd{sl.key, sl.state() == NodeTable::kClosed ? 0ull : f64_bits(sl.cost), q.ftab, 0};
+      });
+    });
+    void* tmp = nullptr;
+    PP_HIP(ctx, hipMalloc(&tmp, total * sizeof(PpFtabUpd)));
+    hipError_t e = hipMemcpyAsync(tmp, all.data(), total * sizeof(PpFtabUpd), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+      pp_ftab_update_launch(ctx, (uint32_t)total, (const PpFtabUpd*)tmp, (unsigned long long*)ctx->ftab_buf, ftab_slots);
+      e = hipStreamSynchronize(s);  // `all` and tmp are about to go
+    }
+    (void)hipFree(tmp);
+    PP_HIP(ctx, e);
+    return PP_OK;
   };
 
   // (2) stage the lane's nodes and launch.  Inputs and outputs are laid out for this round's
@@ -917,6 +1059,16 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     ln.emit.resize(nl);
     ln.nl = nl;
     if (nl == 0) return PP_OK;
+    ++ln.rounds;
+    // a round of few nodes is latency, not host work: it runs without the tables (what they miss
+    // of its news only makes them rule out less)
+    const bool tables = !ftab_off && nl >= kFtabMinLive;
+    if (tables && ln.unassigned && ln.rounds > kFtabStartRound) {
+      const int32_t fst = ftab_assign(ln);
+      if (fst != PP_OK) return fst;
+    }
+    send_updates(ln, tables && ftab_slots != 0);
+    eo.ftab = tables && ftab_slots != 0 ? (const unsigned long long*)ctx->ftab_buf : nullptr;
     ln.pc = nl < 64 ? 1 : 0;
     const size_t depth = std::min<size_t>(kSpecDepth, std::max<size_t>(1, kSpecItems / nl));
     size_t ni = nl;  // one node per query (item = position in the live list) ...
@@ -938,7 +1090,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       return o;
     };
     const size_t r_q = rtake(6 * ni * 8), r_dir = rtake(ni * 8), r_steer = rtake(ni * 8), r_cost = rtake(ni * 8);
-    const size_t r_hid = rtake(ni * 4);
+    const size_t r_hid = rtake(ni * 4), r_fid = rtake(ni * 4);
     const size_t r_in = ro;
     const size_t itn = ni * NP;
     ln.r_shot = rtake(ni * sizeof(PpShotOut));
@@ -950,6 +1102,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     double* hsteer = (double*)(h + r_steer);
     double* hcost = (double*)(h + r_cost);
     int32_t* hhid = (int32_t*)(h + r_hid);
+    int32_t* hfid = (int32_t*)(h + r_fid);
     if (depth == 1) {
       pool.run(nl, [&](size_t k) {  // item = position in the live list, straight from the records
         const Emit& e = ln.emit[k];
@@ -963,6 +1116,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         hsteer[k] = e.steer;
         hcost[k] = e.cost;
         hhid[k] = e.hid;
+        hfid[k] = e.fid;
       }, 64);
     } else {
       pool.run(nl, [&](size_t li) {  // every query fills its own slots
@@ -980,6 +1134,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
           hsteer[k] = n.steer;
           hcost[k] = n.cost;
           hhid[k] = q.hmap_slot;
+          hfid[k] = q.ftab;
         }
       });
     }
@@ -1013,6 +1168,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     eo.end_yaw = (double*)(od + ln.r_arr[6]);
     eo.fcost = (double*)(od + ln.r_arr[7]);
     eo.hmap_id = (const int32_t*)(dd + r_hid);
+    eo.ftab_id = (const int32_t*)(dd + r_fid);
     const double* dq = (const double*)(dd + r_q);
     if (ni < kRoundFusedMax) {
       pp_round_launch(ctx, map, conf, plan, (uint32_t)ni, dq, maxc, (PpShotOut*)(od + ln.r_shot),
@@ -1136,6 +1292,8 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
           }
         o.ids.clear();
         o.emit.clear();
+        send_updates(o, ftab_slots != 0);  // what its last round found out
+        ln.unassigned = true;     // its queries may be without tables
         merged = true;
       }
       if (merged && l == 1) continue;

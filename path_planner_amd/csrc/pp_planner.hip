@@ -312,11 +312,12 @@ class Pool {
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
-  // `chunk` = items a thread takes at a time: small for items that are work, large for trivial ones
-  void run(size_t n, const std::function<void(size_t)>& fn, size_t chunk = 16) {
+  // `chunk` = items a thread takes at a time: small for items that are work, large for trivial ones;
+  // fewer than `serial_below` items run on the calling thread
+  void run(size_t n, const std::function<void(size_t)>& fn, size_t chunk = 16, size_t serial_below = 64) {
     if (n == 0) return;
     chunk_ = chunk;
-    if (th_.empty() || n < 64) {
+    if (th_.empty() || n < serial_below) {
       for (size_t i = 0; i < n; ++i) fn(i);
       return;
     }
@@ -1073,10 +1074,10 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     const size_t depth = std::min<size_t>(kSpecDepth, std::max<size_t>(1, kSpecItems / nl));
     size_t ni = nl;  // one node per query (item = position in the live list) ...
     if (depth > 1) {  // ... unless few queries are left and each also sends nodes it may close soon
+      pool.run(nl, [&](size_t k) { speculate(Q[ln.ids[k]], depth); }, 1, 2);
       ni = 0;
       for (uint32_t id : ln.ids) {
         Query& q = Q[id];
-        speculate(q, depth);
         q.item0 = ni;
         ni += q.want.size();
       }
@@ -1136,7 +1137,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
           hhid[k] = q.hmap_slot;
           hfid[k] = q.ftab;
         }
-      });
+      }, 1, 2);
     }
     const double p2 = prof ? now_ms() : 0.0;
     if (prof) {
@@ -1239,7 +1240,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         q.curr = -1;
       }
       advance_emit(ln, k);  // the next node to expand, while the query's tables are in cache
-    }, 8);
+    }, depth > 1 ? 1 : 8, depth > 1 ? 2 : 64);  // with the look-ahead a query is several nodes' worth of work
     if (need_grids.load(std::memory_order_relaxed)) {
       // (the other lane's round in flight was launched on the bounded grids: whatever of it looked
       // beyond the limit carries the mark and comes back here at that lane's turn)

@@ -251,10 +251,12 @@ def test_large_batch_in_two_lanes_equals_small_batches_and_oracle(ctx):
             assert np.array_equal(big_exp[sl], [int(s.expansions) for s in part["stats"]])
         om = O.OracleMap(ox, oy)
         differ = 0
-        for i in list(range(0, 1500, 47)) + list(np.argsort(big_exp)[-8:]):
+        # (searches still running after 64 rounds have their rollouts pre-filtered on the device by
+        # tables of the cells they have closed or hold open: the longest ones exercise that)
+        for i in list(range(0, 1500, 47)) + list(np.argsort(big_exp)[-40:]):
             e = om.plan(CONF, starts[i], goals[i])
             differ += not same_batch_query(big, int(i), e, 400)
-        assert differ <= 1, differ
+        assert differ <= 2, differ
     finally:
         ctx.set_max_expansions(100000)
         O.set_max_expansions(0)

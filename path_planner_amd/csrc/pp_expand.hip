@@ -137,23 +137,11 @@ int32_t pp_expand_prepare(pp_ctx* ctx, const pp_map* map, const pp_config* conf,
   return PP_OK;
 }
 
-// One lane per record: claim the key's slot (or find it) and lower its value.  Records of one
-// launch may name the same cell more than once; the atomics make the outcome the lowest value.
+// One lane per record.
 __global__ void k_ftab_update(uint32_t n, const PpFtabUpd* __restrict__ upd, unsigned long long* __restrict__ ftab,
                               uint64_t slots) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const PpFtabUpd u = upd[t];
-  unsigned long long* tab = ftab + (uint64_t)u.tab * 2 * slots;
-  uint64_t i = pp_ftab_hash(u.key) & (slots - 1);
-  for (int probe = 0; probe < kFtabProbes; ++probe) {
-    const unsigned long long old = atomicCAS(&tab[2 * i], kFtabEmpty, u.key);
-    if (old == kFtabEmpty || old == u.key) {
-      atomicMin(&tab[2 * i + 1], u.value);  // a fresh slot holds all ones
-      return;
-    }
-    i = (i + 1) & (slots - 1);
-  }
+  if (t < n) pp_ftab_update_one(upd[t], ftab, slots);
 }
 
 void pp_ftab_update_launch(pp_ctx* ctx, uint32_t n, const PpFtabUpd* upd, unsigned long long* ftab, uint64_t slots) {

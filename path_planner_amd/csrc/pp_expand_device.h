@@ -26,6 +26,24 @@ __device__ __forceinline__ double pp_blocked_value(const double* __restrict__ bl
   return blk[t * 1024u + ((k >> 1) * 64u + lane) * 2u + (k & 1u)];
 }
 
+// One record of news for the tables of known cells: claim the key's slot (or find it) and lower
+// its value.  Records that name the same cell, and lookups that run at the same time, are fine:
+// the atomics make the outcome the lowest value, and a lookup that catches a slot between the two
+// steps sees a value above every cost, i.e. rules nothing out.
+__device__ __forceinline__ void pp_ftab_update_one(const PpFtabUpd& u, unsigned long long* __restrict__ ftab,
+                                                   uint64_t slots) {
+  unsigned long long* tab = ftab + (uint64_t)u.tab * 2 * slots;
+  uint64_t i = pp_ftab_hash(u.key) & (slots - 1);
+  for (int probe = 0; probe < kFtabProbes; ++probe) {
+    const unsigned long long old = atomicCAS(&tab[2 * i], kFtabEmpty, u.key);
+    if (old == kFtabEmpty || old == u.key) {
+      atomicMin(&tab[2 * i + 1], u.value);  // a fresh slot holds all ones
+      return;
+    }
+    i = (i + 1) & (slots - 1);
+  }
+}
+
 // Item t = parent t / n_prim, primitive t % n_prim.  pflag, when given, holds the result of the
 // parent's own pose (the first pose of every primitive).
 __device__ __forceinline__ void pp_expand_item(uint64_t t, uint32_t n_prim, const double* __restrict__ px,

@@ -977,11 +977,16 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
                     plan.prm.steer_angle_cost >= 0.0 && plan.prm.steer_change_cost >= 0.0);
   uint64_t ftab_slots = 0;
   uint32_t ftab_tables = 0, ftab_next = 0;
-  auto send_updates = [&](Lane& ln, bool send) {
+  // the records the workers left in the lane's buffer; the buffer starts over
+  auto take_updates = [&](Lane& ln) {
     const uint32_t n = std::min(ln.upd_n.load(std::memory_order_relaxed), ln.upd_fail.load(std::memory_order_relaxed));
-    if (n && send) pp_ftab_update_launch(ctx, n, ln.upd, (unsigned long long*)ctx->ftab_buf, ftab_slots);
     ln.upd_n.store(0, std::memory_order_relaxed);
     ln.upd_fail.store(UINT32_MAX, std::memory_order_relaxed);
+    return n;
+  };
+  auto send_updates = [&](Lane& ln, bool send) {
+    const uint32_t n = take_updates(ln);
+    if (n && send) pp_ftab_update_launch(ctx, n, ln.upd, (unsigned long long*)ctx->ftab_buf, ftab_slots);
   };
   auto ftab_assign = [&](Lane& ln) -> int32_t {
     ln.unassigned = false;
@@ -1068,7 +1073,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       const int32_t fst = ftab_assign(ln);
       if (fst != PP_OK) return fst;
     }
-    send_updates(ln, tables && ftab_slots != 0);
+    // this round's news for the tables: with the round's own launch when that is one kernel
+    uint32_t n_upd = take_updates(ln);
+    if (!(tables && ftab_slots != 0)) n_upd = 0;
     eo.ftab = tables && ftab_slots != 0 ? (const unsigned long long*)ctx->ftab_buf : nullptr;
     ln.pc = nl < 64 ? 1 : 0;
     const size_t depth = std::min<size_t>(kSpecDepth, std::max<size_t>(1, kSpecItems / nl));
@@ -1174,8 +1181,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     if (ni < kRoundFusedMax) {
       pp_round_launch(ctx, map, conf, plan, (uint32_t)ni, dq, maxc, (PpShotOut*)(od + ln.r_shot),
                       (const int64_t*)(dd + r_dir), (const double*)(dd + r_steer), (const double*)(dd + r_cost),
-                      (const double*)d_mot, eo);
+                      (const double*)d_mot, eo, n_upd, ln.upd, (unsigned long long*)ctx->ftab_buf);
     } else {
+      pp_ftab_update_launch(ctx, n_upd, ln.upd, (unsigned long long*)ctx->ftab_buf, ftab_slots);
       PpRsCand* cands = (PpRsCand*)(dw + o_cand) + ln.item_base * PP_RS_MAX_PATHS;
       PpRsPair* pairs = (PpRsPair*)(dw + o_pair) + ln.item_base;
       pp_rs_words_launch(ctx, ni, dq, maxc, cands, pairs);

@@ -639,6 +639,12 @@ struct PpRoundExpand {
   uint32_t n_prim;
   PpExpandParams prm;
   PpExpandDev out;
+  // optional: news for the tables of known cells (pp_expand.h), applied by the first `ub`
+  // workgroups of the launch -- by the time the primitives reach their lookups, at the end of
+  // their rollouts, it is in; a lookup that comes too early only rules out less
+  uint32_t ub = 0, n_upd = 0;
+  const PpFtabUpd* upd = nullptr;
+  unsigned long long* ftab_rw = nullptr;
 };
 
 constexpr int kRoundThreads = 1024;  // sixteen waves: the twelve candidate groups side by side
@@ -648,7 +654,13 @@ k_round(uint32_t n, const double* __restrict__ q6 /* sx sy syaw gx gy gyaw, n ea
         double step_size, uint32_t check_step, PpCostParams cp, PpFootprint f, PpLattice lat, PpBuckets bk,
         int use_lattice, PpShotOut* __restrict__ out, PpRoundExpand e) {
   PP_STAMP(0);
-  if (blockIdx.x < n) {
+  if (blockIdx.x < e.ub) {
+    const uint32_t t = blockIdx.x * kRoundThreads + threadIdx.x;
+    if (t < e.n_upd) pp_ftab_update_one(e.upd[t], e.ftab_rw, e.out.ftab_slots);
+    return;
+  }
+  const uint32_t blk = blockIdx.x - e.ub;
+  if (blk < n) {
     // The pair's words first: wave g < 12 evaluates formula g, its lanes 0..3 the four mirror
     // images; then lane s < 20 of wave 0 runs set_path's duplicate test over the candidates of
     // word s in the reference's order.  Candidates and the pair record stay in LDS for the shot.
@@ -658,7 +670,7 @@ k_round(uint32_t n, const double* __restrict__ q6 /* sx sy syaw gx gy gyaw, n ea
     __shared__ uint32_t s_fl;
     __shared__ PpRsPair s_pair;
     __shared__ double s_start[3];
-    const uint32_t i = blockIdx.x, wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
+    const uint32_t i = blk, wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
     if (threadIdx.x == 0) {
       s_acc = 0ull;
       s_fl = 0u;
@@ -700,8 +712,8 @@ k_round(uint32_t n, const double* __restrict__ q6 /* sx sy syaw gx gy gyaw, n ea
     return;
   }
   const uint64_t items = (uint64_t)n * e.n_prim;
-  const uint64_t stride = (uint64_t)(gridDim.x - n) * kRoundThreads;
-  for (uint64_t t = (uint64_t)(blockIdx.x - n) * kRoundThreads + threadIdx.x; t < items; t += stride)
+  const uint64_t stride = (uint64_t)(gridDim.x - e.ub - n) * kRoundThreads;
+  for (uint64_t t = (uint64_t)(blk - n) * kRoundThreads + threadIdx.x; t < items; t += stride)
     pp_expand_item(t, e.n_prim, e.px, e.py, e.pyaw, e.pdir, e.psteer, e.pcost, e.motion, e.prm, f, lat, bk,
                    use_lattice, nullptr, e.out);
 }
@@ -878,7 +890,8 @@ void pp_rs_shot_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, ui
 
 void pp_round_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, const PpExpandPlan& plan, uint32_t n,
                      const double* d_q, double maxc, PpShotOut* d_out, const int64_t* d_pdir,
-                     const double* d_psteer, const double* d_pcost, const double* d_motion, PpExpandDev eo) {
+                     const double* d_psteer, const double* d_pcost, const double* d_motion, PpExpandDev eo,
+                     uint32_t n_upd, const PpFtabUpd* upd, unsigned long long* ftab) {
   if (n == 0) return;
   PpFootprint f = pp_make_footprint(conf);
   uint32_t cs = (uint32_t)std::min<uint64_t>(conf->collision_check_step, 0x7fffffffu);
@@ -895,7 +908,13 @@ void pp_round_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, cons
   e.out = eo;
   const uint64_t items = (uint64_t)n * plan.n_prim;
   const unsigned eb = (unsigned)((items + kRoundThreads - 1) / kRoundThreads);
-  hipLaunchKernelGGL(k_round, dim3(n + eb), dim3(kRoundThreads), 0, ctx->stream, n, d_q, maxc, conf->move_step, cs,
+  if (n_upd && upd && ftab) {
+    e.n_upd = n_upd;
+    e.ub = (n_upd + kRoundThreads - 1) / kRoundThreads;
+    e.upd = upd;
+    e.ftab_rw = ftab;
+  }
+  hipLaunchKernelGGL(k_round, dim3(e.ub + n + eb), dim3(kRoundThreads), 0, ctx->stream, n, d_q, maxc, conf->move_step, cs,
                      cost_params(conf), f, map->lat, map->bk, map->lattice ? 1 : 0, d_out, e);
 }
 

@@ -235,3 +235,33 @@ def test_relax_band_does_not_change_the_result(ctx):
     st, exp = O.wavefront(obs, gx, gy)
     for o in outs:
         assert (o.view(np.uint64) == exp.view(np.uint64)).all()
+
+
+def test_whole_grid_session_equals_the_dense_entry_point(ctx):
+    """A slab session over all columns keeps the grid in the relaxation's own layout (raster packed
+    once, nothing unpacked until asked): what it reads out equals pp_wavefront_dev, also after a
+    reset onto another raster."""
+    import torch
+    from path_planner_amd.tiled import DeviceSlabSolver, make_slab
+    n = 300
+    sess = None
+    for seed in (5, 6):
+        obs, gx, gy = W.wavefront_obsmap(n, 0.25, seed=seed)
+        d_obs = torch.from_numpy(obs).cuda()
+        cost = torch.empty((n, n), dtype=torch.float64, device="cuda")
+        api.wavefront_dev(ctx, d_obs, gx, gy, cost)
+        ctx.synchronize()
+        slab_obs, _ = make_slab(obs, n, n, 0, n, "cuda")
+        torch.cuda.synchronize()
+        if sess is None:
+            sess = DeviceSlabSolver(ctx, n, n, 0, n, slab_obs, (gx, gy))
+        else:
+            assert (gx, gy) == goal  # the session keeps its goal
+            sess.reset(slab_obs)
+        goal = (gx, gy)
+        assert sess.step(None, None, float("inf")) == float("inf")
+        out = sess.read()
+        torch.cuda.synchronize()
+        assert torch.equal(out[1:-1], cost)
+        assert bool(torch.isinf(out[0]).all()) and bool(torch.isinf(out[-1]).all())
+    sess.close()

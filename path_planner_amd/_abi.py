@@ -160,6 +160,7 @@ def load_library(path=None):
                                        C.c_uint64, C.POINTER(vp)]),
         "pp_slab_relax": (C.c_int32, [vp, vp, vp, C.c_double, vp, vp, d, u64]),
         "pp_slab_read": (C.c_int32, [vp, vp]),
+        "pp_slab_gather": (C.c_int32, [vp, C.c_uint64, vp, vp, vp]),
         "pp_slab_reset": (C.c_int32, [vp, vp]),
         "pp_slab_destroy": (None, [vp]),
         "pp_rs_batch": (C.c_int32, [vp, C.c_uint64, d, d, d, d, d, d, C.c_double, i32, i32,

@@ -861,6 +861,21 @@ __global__ void k_slab_edges(TileGrid g, uint64_t yw, uint64_t col_first, uint64
   }
 }
 
+// Cells (x[i], y[i]) in global coordinates from the blocked array; stored column = x - gx_off.
+__global__ void k_slab_gather(TileGrid g, uint64_t n, int64_t gx_off, uint64_t ncols, uint64_t yw,
+                              const uint64_t* __restrict__ x, const uint64_t* __restrict__ y,
+                              double* __restrict__ out, uint32_t* __restrict__ bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t col = (int64_t)x[i] - gx_off;
+  if (col < 0 || col >= (int64_t)ncols || y[i] >= yw) {
+    out[i] = __longlong_as_double((long long)kInfBits);
+    *bad = 1u;
+    return;
+  }
+  out[i] = tile_cell_value(g, col, (int64_t)y[i]);
+}
+
 struct TileRun {
   TileGrid g{};
   TileWork w{};
@@ -1259,6 +1274,23 @@ extern "C" int32_t pp_slab_relax(pp_slab* s, const double* d_halo_lo_new, const 
   if (pending) *pending = std::min(left[0], left[1]);
   if (iters) *iters = rounds - round0;
   return PP_OK;
+}
+
+extern "C" int32_t pp_slab_gather(pp_slab* s, uint64_t n, const uint64_t* d_x, const uint64_t* d_y, double* d_out) {
+  if (!s) return PP_ERR_INVALID;
+  if (n == 0) return PP_OK;
+  if (!d_x || !d_y || !d_out) return PP_ERR_INVALID;
+  pp_ctx* ctx = s->ctx;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  uint32_t* bad = (uint32_t*)((char*)s->run.w.count + 200);  // a spare word of the session's counters
+  PP_HIP(ctx, hipMemsetAsync(bad, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(k_slab_gather, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 30)), dim3(256), 0,
+                     ctx->stream, s->run.g, n, s->d.gx_off, s->d.ncols, s->d.yw, d_x, d_y, d_out, bad);
+  PP_HIP(ctx, hipGetLastError());
+  uint32_t flag = 0;
+  PP_HIP(ctx, hipMemcpyAsync(&flag, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return flag ? PP_ERR_BOUNDS : PP_OK;
 }
 
 extern "C" int32_t pp_slab_read(pp_slab* s, double* d_cost_slab) {

@@ -111,6 +111,18 @@ class DeviceSlabSolver:
             raise PlannerError(st, "pp_slab_read")
         return cost
 
+    def gather(self, x, y):
+        """Costs of the global cells (x[i], y[i]) (device int64 / uint64 tensors) straight from the
+        working copy."""
+        assert x.is_cuda and y.is_cuda and x.shape == y.shape and x.dtype in (torch.int64, torch.uint64)
+        x, y = x.contiguous(), y.contiguous()
+        out = torch.empty(x.shape, dtype=torch.float64, device=self.device)
+        torch.cuda.synchronize(self.device)
+        st = self.ctx.lib.pp_slab_gather(self.h, x.numel(), x.data_ptr(), y.data_ptr(), out.data_ptr())
+        if st != A.PP_OK:
+            raise PlannerError(st, "pp_slab_gather")
+        return out
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.pp_slab_destroy(self.h)

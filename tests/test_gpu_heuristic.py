@@ -264,4 +264,12 @@ def test_whole_grid_session_equals_the_dense_entry_point(ctx):
         torch.cuda.synchronize()
         assert torch.equal(out[1:-1], cost)
         assert bool(torch.isinf(out[0]).all()) and bool(torch.isinf(out[-1]).all())
+        # single cells straight from the working copy
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        xs = torch.randint(0, n, (5000,), generator=g).cuda()
+        ys = torch.randint(0, n, (5000,), generator=g).cuda()
+        assert torch.equal(sess.gather(xs, ys), cost[xs, ys])
+    with pytest.raises(api.PlannerError) as e:
+        sess.gather(torch.tensor([n + 1], device="cuda"), torch.tensor([0], device="cuda"))
+    assert e.value.status == A.PP_ERR_BOUNDS
     sess.close()

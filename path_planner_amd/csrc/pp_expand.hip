@@ -26,7 +26,8 @@ k_parent_pose(uint64_t n, const double* __restrict__ px, const double* __restric
   flag[p] = (uint8_t)r;
 }
 
-__global__ void __launch_bounds__(256)
+// (four waves per SIMD: the table lookup of pp_expand_item would otherwise cost one register too many)
+__global__ void __launch_bounds__(256, 4)
 k_expand(uint64_t n_items, uint32_t n_prim, const double* __restrict__ px,
          const double* __restrict__ py, const double* __restrict__ pyaw,
          const int64_t* __restrict__ pdir, const double* __restrict__ psteer,

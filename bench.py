@@ -455,6 +455,11 @@ def main():
 
     stream = torch.cuda.Stream(device=dev)
     ctx = api.Context(dev_index, stream.cuda_stream)
+    # the planner's worker threads spin between rounds: several ranks on one node share its cores
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    if local_world > 1:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 16)
+        ctx.set_host_threads(max(1, min(15, cores // local_world - 1)))
     conf = A.demo_config()
     if args.car == "compact":
         conf.car.center2front, conf.car.center2back, conf.car.width, conf.extend_bound = 3.0, 1.0, 1.8, 0.2

@@ -55,6 +55,10 @@ class Context:
         """Memory budget of plan_batch's joint heuristic relaxation (default 8 GiB)."""
         _chk(self.lib.pp_ctx_set_heuristic_workspace(self.h, int(nbytes)), "pp_ctx_set_heuristic_workspace")
 
+    def set_host_threads(self, n):
+        """Worker threads plan_batch may start beside the calling thread (default 15)."""
+        _chk(self.lib.pp_ctx_set_host_threads(self.h, int(n)), "pp_ctx_set_host_threads")
+
     def synchronize(self):
         _chk(self.lib.pp_ctx_synchronize(self.h), "pp_ctx_synchronize")
 

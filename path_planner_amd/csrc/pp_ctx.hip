@@ -100,6 +100,12 @@ extern "C" int32_t pp_ctx_set_heuristic_workspace(pp_ctx* ctx, uint64_t bytes) {
   return PP_OK;
 }
 
+extern "C" int32_t pp_ctx_set_host_threads(pp_ctx* ctx, uint32_t n) {
+  if (!ctx) return PP_ERR_INVALID;
+  ctx->host_threads = std::min<uint32_t>(n, 255);
+  return PP_OK;
+}
+
 extern "C" int32_t pp_last_hip_error(pp_ctx* ctx) { return ctx ? ctx->last_hip_error : 0; }
 
 int32_t pp_scratch_reserve(pp_ctx* ctx, size_t bytes) {

@@ -69,6 +69,7 @@ struct pp_ctx {
   int num_cus = 256;
   uint64_t max_expansions = 100000;  // per query, 0 = unlimited
   uint64_t heuristic_pass_blocks = (uint64_t)1 << 20;  // 32x32-cell blocks one relaxation of several grids may hold (8 KiB each)
+  uint32_t host_threads = 15;        // worker threads pp_plan_batch may start beside the calling thread
   double heuristic_limit = -1.0;     // cost limit of the planner's first heuristic relaxation, < 0 = automatic
   // reusable device scratch (grown on demand, never shrunk)
   void* scratch = nullptr;

@@ -395,6 +395,7 @@ class Pool {
 struct PlanState {
   std::vector<Query> queries;
   std::unique_ptr<Pool> pool;
+  unsigned pool_workers = 0;
   hipEvent_t lane_done[2] = {nullptr, nullptr};  // a lane's results have reached the pinned area
   ~PlanState() {
     for (hipEvent_t e : lane_done)
@@ -713,11 +714,14 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   };
 
   unsigned hw = std::thread::hardware_concurrency();
-  unsigned workers = nq >= 128 ? std::min(15u, hw > 1 ? hw - 1 : 0u) : 0u;
+  unsigned workers = nq >= 128 ? std::min((unsigned)ctx->host_threads, hw > 1 ? hw - 1 : 0u) : 0u;
   // the worker threads are started once per context (they sleep between batches); a small batch
   // runs on the calling thread alone
   Pool serial(0);
-  if (workers && !state.pool) state.pool.reset(new Pool(workers));
+  if (workers && (!state.pool || state.pool_workers != workers)) {
+    state.pool.reset(new Pool(workers));
+    state.pool_workers = workers;
+  }
   Pool& pool = workers ? *state.pool : serial;
   for (hipEvent_t& e : state.lane_done)
     if (!e) PP_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));

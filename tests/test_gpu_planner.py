@@ -367,3 +367,28 @@ def test_heuristic_grids_in_several_passes(ctx):
         ctx.set_heuristic_workspace(8 << 30)
         ctx.set_max_expansions(100000)
         O.set_max_expansions(0)
+
+
+def test_host_thread_count_does_not_change_a_batch(ctx):
+    """pp_ctx_set_host_threads only says how many threads apply a round's results."""
+    ox, oy = W.demo_obstacles()
+    m = api.ObstacleMap(ctx, ox, oy)
+    rng = np.random.default_rng(77)
+    n = 300
+    starts = np.column_stack([rng.uniform(4, 46, n), rng.uniform(4, 26, n), rng.uniform(-3, 3, n)])
+    goals = np.column_stack([rng.uniform(4, 46, n), rng.uniform(4, 26, n), rng.uniform(-3, 3, n)])
+    ctx.set_max_expansions(150)
+    runs = []
+    try:
+        for threads in (15, 0, 3):
+            ctx.set_host_threads(threads)
+            r = api.plan_batch(ctx, m, CONF, starts, goals, cap=1024, closed_cap=150)
+            runs.append({k: np.array(r[k], copy=True) for k in ("status", "len", "cost", "x", "y", "yaw", "dir", "closed")})
+            runs[-1]["exp"] = np.array([int(s.expansions) for s in r["stats"]])
+    finally:
+        ctx.set_host_threads(15)
+        ctx.set_max_expansions(100000)
+    assert (runs[0]["status"] == 0).sum() > 20
+    for r in runs[1:]:
+        for k, v in runs[0].items():
+            assert np.array_equal(v, r[k], equal_nan=True), k

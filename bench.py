@@ -24,13 +24,16 @@ With the default workload on one GPU the same line carries, under "extra", short
 of the other BASELINE configs (rs 1 M pairs, wavefront 16384^2, 4096 queries on 4096^2 in its
 light and its search-heavy form), each with its own ms_per_step, roofline and cpu_baseline; they
 run after the timed region of the headline workload and do not touch its numbers (--no-extra
-skips them).
+skips them).  With N > 1 the extra legs are the two workloads that shard for real -- the 4096
+queries dealt round-robin and the 16384^2 grid in x-slabs with its halo exchange -- under a
+watchdog (--extra-timeout): a leg that does not return never costs the headline line.
 """
 import argparse
 import json
 import math
 import os
 import sys
+import threading
 import time
 from types import SimpleNamespace
 
@@ -76,6 +79,8 @@ def parse():
                     help="wavefront obstacle raster: Bernoulli(0.2) or long walls with one gap each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs of the default run")
+    ap.add_argument("--extra-timeout", type=float, default=240.0,
+                    help="seconds the extra legs of a multi-rank run may take before the line is printed without them")
     ap.add_argument("--cpu-sample", type=int, default=0)
     return ap.parse_args()
 
@@ -535,8 +540,46 @@ def main():
                 out["extra"][name] = {"error": f"{type(ex).__name__}: {ex}"}
             ctx.set_max_expansions(100000)
             torch.cuda.empty_cache()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    # With several ranks the two workloads that are sharded for real follow: the 4096 queries dealt
+    # round-robin and the 16384^2 heuristic grid in x-slabs with its halo exchange.  They run under a
+    # watchdog: if a leg has not returned in time (a collective that never completes), every rank
+    # leaves by itself and rank 0 prints the line with what it has, the headline number first of all.
+    printed = threading.Lock()
+
+    def emit():
+        if printed.acquire(blocking=False) and rank == 0:
+            print(json.dumps(out), flush=True)
+
+    if args.workload == "collision" and world > 1 and not args.no_extra:
+        del wl
+        torch.cuda.empty_cache()
+        out["extra"] = {}
+
+        def give_up():
+            out["extra"]["watchdog"] = f"extra legs stopped after {args.extra_timeout} s"
+            emit()
+            os._exit(0)
+        dog = threading.Timer(args.extra_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        for name, over, steps, warmup in [("queries", {"workload": "queries"}, 2, 1),
+                                          ("wavefront", {"workload": "wavefront"}, 2, 1)]:
+            a = argparse.Namespace(**{**vars(parse_defaults()), **over, "no_cpu_baseline": True})
+            try:
+                w2 = BUILDERS[a.workload](a, E)
+                el, dms = timed(w2, steps, warmup)
+                t = torch.tensor([el], dtype=torch.float64, device=rdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tu = torch.tensor([w2.units], dtype=torch.int64, device=rdev)
+                dist.all_reduce(tu)
+                out["extra"][name] = line(w2, a, steps, warmup, float(t.item()), dms, int(tu.item()) * steps)
+                del w2
+            except Exception as ex:  # the same failure on every rank: the next leg still runs
+                out["extra"][name] = {"error": f"{type(ex).__name__}: {ex}"}
+            ctx.set_max_expansions(100000)
+            torch.cuda.empty_cache()
+        dog.cancel()
+    emit()
     if world > 1:
         dist.destroy_process_group()
 

@@ -3,7 +3,7 @@
 set -u
 tag=${1:-k2traffic}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$tag; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
-run() { name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $O/$name -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/$name.log 2>&1 || { echo "$name failed"; tail -3 $O/$name.log; exit 1; }; }
+run() { name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $O/$name -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 > $O/$name.log 2>&1 || { echo "$name failed"; tail -3 $O/$name.log; exit 1; }; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_WRITE_sum

@@ -13,7 +13,7 @@ case ${1:-build} in
         -Xarch_host -fsanitize=address -Xarch_host -fno-omit-frame-pointer -c $C/$f.hip -o lab/asan_$f.o &
     done
     wait
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fno-gpu-sanitize -fsanitize=address -o lab/libpp_asan.so lab/asan_*.o $C/pp_lut.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fno-gpu-sanitize -fsanitize=address -o lab/libpp_asan.so lab/asan_*.o
     /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fno-gpu-sanitize -fsanitize=address -fno-omit-frame-pointer -I include tools/asan_planner.cpp \
       -o lab/asan_planner -L lab -lpp_asan -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
     rm -f lab/asan_*.o

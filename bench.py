@@ -564,7 +564,8 @@ def main():
         dog.start()
         for name, over, steps, warmup in [("queries", {"workload": "queries"}, 2, 1),
                                           ("wavefront", {"workload": "wavefront"}, 2, 1)]:
-            a = argparse.Namespace(**{**vars(parse_defaults()), **over, "no_cpu_baseline": True})
+            # sizes as given on the command line (the BASELINE sizes unless a rehearsal shrinks them)
+            a = argparse.Namespace(**{**vars(args), **over, "no_cpu_baseline": True})
             try:
                 w2 = BUILDERS[a.workload](a, E)
                 el, dms = timed(w2, steps, warmup)

@@ -65,3 +65,27 @@ def test_sharded_units_gloo_host_engine(world):
 def test_sharded_units_device():
     out = _run(2, "--mode", "device", "--poses", "200000", "--pairs", "20000", "--queries", "33")
     assert "poses=same" in out and "pairs=same" in out and "queries=same" in out
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_line_carries_the_sharded_legs():
+    """The default bench run with two ranks (gloo, both on the one card, sizes shrunk): one JSON line
+    whose headline is the pose-sharded collision check and whose `extra` holds the query-sharded
+    planner and the slab wavefront with its halo exchange."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--poses", "2097152", "--queries", "256", "--map", "1024", "--goals", "8", "--cells", "2048"]
+    env = dict(os.environ, PP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["poses_per_gpu"] == 2097152
+    ex = d["extra"]
+    assert "watchdog" not in ex, ex
+    assert ex["queries"]["value"] > 0 and ex["queries"]["search"]["other_errors"] == 0, ex["queries"]
+    assert ex["queries"]["config"]["parallelism"] == "query-sharded x2"
+    assert ex["wavefront"]["value"] > 0 and ex["wavefront"]["config"]["exchange_rounds"] >= 1, ex["wavefront"]

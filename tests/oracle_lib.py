@@ -76,7 +76,7 @@ class OracleMap:
         self.h = lib().orc_map_create(_p(self.ox), _p(self.oy), len(self.ox))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:  # module globals are gone at interpreter exit
             lib().orc_map_destroy(self.h)
             self.h = None
 

@@ -1,5 +1,6 @@
 """Parity soak on seeds the test suite does not use (GPU box): the collision, Reeds-Shepp, heuristic and
-planner paths against the CPU oracle with the tests' own checkers.  usage: tools/soak.py [rounds]
+planner paths against the CPU oracle with the tests' own checkers.  usage: tests/soak.py [rounds]
+(not collected by pytest: a longer run of the same checks, started by hand)
 Prints one line per item and a summary; exits non-zero at the first difference a guard band does
 not account for."""
 import math
@@ -12,7 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import oracle_lib as O  # noqa: E402
 from path_planner_amd import _abi as A  # noqa: E402
 from path_planner_amd import api  # noqa: E402

@@ -120,4 +120,82 @@ for r in range(rounds):
         O.set_max_expansions(0)
     say(f"round {r}: planner {nq} queries on a {msz}^2 map: {found} found, {differ} differ after a guard-band decision")
 
+# ---- other Configs than the demo's: resolutions, steer set, step sizes, cost weights
+for r in range(rounds):
+    seed = 0xC0F16000 + 613 * r
+    rng = np.random.default_rng(seed)
+    conf = A.demo_config()
+    conf.xy_reso = float(rng.choice([1.0, 1.5, 2.0, 3.0]))
+    conf.yaw_reso = math.radians(float(rng.choice([5.0, 10.0, 15.0, 22.5])))
+    conf.move_step = float(rng.choice([0.2, 0.3, 0.4, 0.7]))
+    conf.n_steer = int(rng.choice([4, 10, 20, 33]))
+    conf.collision_check_step = int(rng.choice([1, 3, 5, 8]))
+    conf.extend_bound = float(rng.choice([0.3, 0.8, 1.4]))
+    conf.gear_cost = float(rng.choice([0.0, 10.0, 100.0]))
+    conf.backward_cost = float(rng.choice([1.0, 5.0]))
+    conf.steer_change_cost = float(rng.choice([0.0, 5.0]))
+    conf.steer_angle_cost = float(rng.choice([0.0, 1.0]))
+    conf.h_cost = float(rng.choice([1.0, 5.0, 15.0]))
+    conf.max_steer = float(rng.choice([0.4, 0.6, 0.8]))
+    conf.car.wheel_base = float(rng.choice([2.5, 3.5]))
+    desc = (f"xy {conf.xy_reso} yaw {math.degrees(conf.yaw_reso):.1f} step {conf.move_step} n_steer {conf.n_steer} "
+            f"check {conf.collision_check_step} ext {conf.extend_bound}")
+    msz = int(rng.integers(100, 180))
+    occ = W.occupancy_grid(msz, float(rng.choice([0.002, 0.005])), seed=seed + 3)
+    ox, oy = W.raster_to_points(occ)
+    m = api.ObstacleMap(ctx, raster=occ)
+    om = O.OracleMap(ox, oy)
+    # rollouts
+    n = 400
+    px, py = rng.uniform(3, msz - 4, n), rng.uniform(3, msz - 4, n)
+    pyaw = rng.uniform(-2 * math.pi, 2 * math.pi, n)
+    pdir = rng.choice([-1, 1], n)
+    steer, _ = api.calc_motion_set(conf)
+    psteer = rng.choice(steer, n)
+    pcost = rng.uniform(0, 500, n)
+    got = api.expand(ctx, m, conf, px, py, pyaw, pdir, psteer, pcost)
+    st, exp = om.expand(conf, px, py, pyaw, pdir, psteer, pcost)
+    assert st == 0
+    amb = (got["valid"] & 2) != 0
+    assert amb.sum() <= 4, amb.sum()
+    ok = ~amb
+    assert ((got["valid"] & 1)[ok] == exp["valid"][ok]).all()
+    v = ok & (exp["valid"] == 1)
+    for k in ("xind", "yind", "yawind"):
+        assert (got[k][v] == exp[k][v]).all(), k
+    assert (got["cost"][v] == exp["cost"][v]).all()
+    assert (got["end_yaw"][v] == exp["end_yaw"][v]).all()
+    assert np.allclose(got["end_x"][v], exp["end_x"][v], rtol=1e-12, atol=1e-12)
+    assert np.allclose(got["end_y"][v], exp["end_y"][v], rtol=1e-12, atol=1e-12)
+    # analytic shots
+    ns = 300
+    s = np.c_[rng.uniform(3, msz - 4, ns), rng.uniform(3, msz - 4, ns), rng.uniform(-math.pi, math.pi, ns)]
+    g = np.c_[rng.uniform(3, msz - 4, ns), rng.uniform(3, msz - 4, ns), rng.uniform(-math.pi, math.pi, ns)]
+    g[: ns // 2] = s[: ns // 2] + rng.uniform(-25, 25, (ns // 2, 3)) * [1, 1, 0.1]
+    found, idx, npaths, words, cost = api.analytic_expansion(ctx, m, conf, s, g)
+    st, efound, eidx, enp, ewords, ecost = om.analytic(conf, s, g)
+    oks = (found & 2) == 0
+    assert ((found & 1)[oks] == (efound & 1)[oks]).all()
+    assert (idx[oks] == eidx[oks]).all() and (npaths[oks] == enp[oks]).all()
+    assert np.allclose(cost[oks], ecost[oks], rtol=1e-9, atol=0)
+    assert (np.abs(npaths[~oks] - enp[~oks]) <= 1).all()
+    # planner
+    nq = 32
+    starts = np.c_[rng.uniform(12, msz - 12, nq), rng.uniform(12, msz - 12, nq), rng.uniform(-3, 3, nq)]
+    goals = np.c_[rng.uniform(15, msz - 15, 4), rng.uniform(15, msz - 15, 4), rng.uniform(-3, 3, 4)][rng.integers(0, 4, nq)]
+    ctx.set_max_expansions(800)
+    O.set_max_expansions(800)
+    try:
+        res = api.plan_batch(ctx, m, conf, starts, goals, cap=40000, closed_cap=1 << 12)
+        differ = found_n = 0
+        for i in range(nq):
+            e = om.plan(conf, starts[i], goals[i])
+            differ += not TP.same_batch_query(res, i, e, 1 << 12)
+            found_n += res["status"][i] == 0
+    finally:
+        ctx.set_max_expansions(100000)
+        O.set_max_expansions(0)
+    say(f"config {r} ({desc}): rollouts of {n} parents equal ({int(v.sum())} valid, {int(amb.sum())} in the guard band), "
+        f"{ns} shots equal ({int((~oks).sum())} flagged), planner {found_n}/{nq} found, {differ} differ after a guard-band decision")
+
 say("soak done")

@@ -392,3 +392,70 @@ def test_host_thread_count_does_not_change_a_batch(ctx):
     for r in runs[1:]:
         for k, v in runs[0].items():
             assert np.array_equal(v, r[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("xy,yaw_deg,step,n_steer,check,extend,maxs,hc", [
+    (1.0, 22.5, 0.2, 20, 3, 1.4, 0.6, 15.0),
+    (3.0, 5.0, 0.7, 10, 8, 0.8, 0.8, 5.0),
+    (1.5, 10.0, 0.3, 4, 1, 0.3, 0.4, 1.0),
+    (2.0, 15.0, 0.4, 33, 5, 1.4, 0.6, 15.0),
+])
+def test_other_configs_vs_oracle(ctx, xy, yaw_deg, step, n_steer, check, extend, maxs, hc):
+    """Rollouts, analytic shots and a planner batch under Configs other than the demo's: grid and
+    yaw resolution, step size (hence poses per primitive), steer set, check step, bound, steering
+    limit and heuristic weight all differ from src/main.rs:216-230."""
+    conf = A.demo_config()
+    conf.xy_reso, conf.yaw_reso, conf.move_step = xy, math.radians(yaw_deg), step
+    conf.n_steer, conf.collision_check_step, conf.extend_bound = n_steer, check, extend
+    conf.max_steer, conf.h_cost, conf.gear_cost, conf.steer_change_cost = maxs, hc, 10.0, 0.0
+    rng = np.random.default_rng(int(xy * 1000 + n_steer))
+    msz = 140
+    occ = W.occupancy_grid(msz, 0.004, seed=4242 + n_steer)
+    ox, oy = W.raster_to_points(occ)
+    m = api.ObstacleMap(ctx, raster=occ)
+    om = O.OracleMap(ox, oy)
+    n = 300
+    px, py = rng.uniform(3, msz - 4, n), rng.uniform(3, msz - 4, n)
+    pyaw = rng.uniform(-2 * math.pi, 2 * math.pi, n)
+    pdir = rng.choice([-1, 1], n)
+    steer, _ = api.calc_motion_set(conf)
+    assert len(steer) == 2 * (2 * n_steer - 1)
+    psteer = rng.choice(steer, n)
+    pcost = rng.uniform(0, 500, n)
+    got = api.expand(ctx, m, conf, px, py, pyaw, pdir, psteer, pcost)
+    st, exp = om.expand(conf, px, py, pyaw, pdir, psteer, pcost)
+    assert st == 0
+    amb = (got["valid"] & 2) != 0
+    assert amb.sum() <= 2
+    ok = ~amb
+    assert ((got["valid"] & 1)[ok] == exp["valid"][ok]).all()
+    v = ok & (exp["valid"] == 1)
+    assert v.sum() > 500
+    for k in ("xind", "yind", "yawind"):
+        assert (got[k][v] == exp[k][v]).all(), k
+    assert (got["cost"][v] == exp["cost"][v]).all() and (got["end_yaw"][v] == exp["end_yaw"][v]).all()
+    ns = 200
+    s = np.c_[rng.uniform(3, msz - 4, ns), rng.uniform(3, msz - 4, ns), rng.uniform(-math.pi, math.pi, ns)]
+    g = s + rng.uniform(-25, 25, (ns, 3)) * [1, 1, 0.1]
+    found, idx, npaths, words, cost = api.analytic_expansion(ctx, m, conf, s, g)
+    st, efound, eidx, enp, ewords, ecost = om.analytic(conf, s, g)
+    oks = (found & 2) == 0
+    assert oks.mean() > 0.9
+    assert ((found & 1)[oks] == (efound & 1)[oks]).all() and (idx[oks] == eidx[oks]).all()
+    assert (npaths[oks] == enp[oks]).all() and np.allclose(cost[oks], ecost[oks], rtol=1e-9, atol=0)
+    nq = 24
+    starts = np.c_[rng.uniform(12, msz - 12, nq), rng.uniform(12, msz - 12, nq), rng.uniform(-3, 3, nq)]
+    goals = np.c_[rng.uniform(15, msz - 15, 3), rng.uniform(15, msz - 15, 3), rng.uniform(-3, 3, 3)][rng.integers(0, 3, nq)]
+    ctx.set_max_expansions(800)
+    O.set_max_expansions(800)
+    try:
+        res = api.plan_batch(ctx, m, conf, starts, goals, cap=40000, closed_cap=1 << 12)
+        differ = found_n = 0
+        for i in range(nq):
+            e = om.plan(conf, starts[i], goals[i])
+            differ += not same_batch_query(res, i, e, 1 << 12)
+            found_n += res["status"][i] == 0
+    finally:
+        ctx.set_max_expansions(100000)
+        O.set_max_expansions(0)
+    assert differ == 0 and found_n >= nq // 3, (differ, found_n)

@@ -143,11 +143,23 @@ for r in range(rounds):
     msz = int(rng.integers(100, 180))
     occ = W.occupancy_grid(msz, float(rng.choice([0.002, 0.005])), seed=seed + 3)
     ox, oy = W.raster_to_points(occ)
-    m = api.ObstacleMap(ctx, raster=occ)
+    ox, oy = np.asarray(ox, np.float64), np.asarray(oy, np.float64)
+    shift = 0.0
+    kind = "lattice"
+    if r % 3 == 1:    # obstacle points off the lattice: the bucket-grid form of the footprint test
+        ox = ox + rng.uniform(-0.3, 0.3, len(ox))
+        oy = oy + rng.uniform(-0.3, 0.3, len(oy))
+        kind = "points"
+    elif r % 3 == 2:  # part of the map at negative coordinates (the crate's `as usize` saturates there)
+        shift = -float(rng.integers(20, 60))
+        ox, oy = ox + shift, oy + shift
+        kind = f"lattice shifted by {shift:.0f}"
+    m = api.ObstacleMap(ctx, ox, oy)
     om = O.OracleMap(ox, oy)
+    desc += f", {kind}"
     # rollouts
     n = 400
-    px, py = rng.uniform(3, msz - 4, n), rng.uniform(3, msz - 4, n)
+    px, py = rng.uniform(3, msz - 4, n) + shift, rng.uniform(3, msz - 4, n) + shift
     pyaw = rng.uniform(-2 * math.pi, 2 * math.pi, n)
     pdir = rng.choice([-1, 1], n)
     steer, _ = api.calc_motion_set(conf)
@@ -169,8 +181,8 @@ for r in range(rounds):
     assert np.allclose(got["end_y"][v], exp["end_y"][v], rtol=1e-12, atol=1e-12)
     # analytic shots
     ns = 300
-    s = np.c_[rng.uniform(3, msz - 4, ns), rng.uniform(3, msz - 4, ns), rng.uniform(-math.pi, math.pi, ns)]
-    g = np.c_[rng.uniform(3, msz - 4, ns), rng.uniform(3, msz - 4, ns), rng.uniform(-math.pi, math.pi, ns)]
+    s = np.c_[rng.uniform(3, msz - 4, ns) + shift, rng.uniform(3, msz - 4, ns) + shift, rng.uniform(-math.pi, math.pi, ns)]
+    g = np.c_[rng.uniform(3, msz - 4, ns) + shift, rng.uniform(3, msz - 4, ns) + shift, rng.uniform(-math.pi, math.pi, ns)]
     g[: ns // 2] = s[: ns // 2] + rng.uniform(-25, 25, (ns // 2, 3)) * [1, 1, 0.1]
     found, idx, npaths, words, cost = api.analytic_expansion(ctx, m, conf, s, g)
     st, efound, eidx, enp, ewords, ecost = om.analytic(conf, s, g)
@@ -181,8 +193,8 @@ for r in range(rounds):
     assert (np.abs(npaths[~oks] - enp[~oks]) <= 1).all()
     # planner
     nq = 32
-    starts = np.c_[rng.uniform(12, msz - 12, nq), rng.uniform(12, msz - 12, nq), rng.uniform(-3, 3, nq)]
-    goals = np.c_[rng.uniform(15, msz - 15, 4), rng.uniform(15, msz - 15, 4), rng.uniform(-3, 3, 4)][rng.integers(0, 4, nq)]
+    starts = np.c_[rng.uniform(12, msz - 12, nq) + shift, rng.uniform(12, msz - 12, nq) + shift, rng.uniform(-3, 3, nq)]
+    goals = np.c_[rng.uniform(15, msz - 15, 4) + shift, rng.uniform(15, msz - 15, 4) + shift, rng.uniform(-3, 3, 4)][rng.integers(0, 4, nq)]
     ctx.set_max_expansions(800)
     O.set_max_expansions(800)
     try:
@@ -192,9 +204,11 @@ for r in range(rounds):
             e = om.plan(conf, starts[i], goals[i])
             differ += not TP.same_batch_query(res, i, e, 1 << 12)
             found_n += res["status"][i] == 0
+        errs = int((res["status"] < 0).sum())
     finally:
         ctx.set_max_expansions(100000)
         O.set_max_expansions(0)
+    desc += f", {errs} error statuses"
     say(f"config {r} ({desc}): rollouts of {n} parents equal ({int(v.sum())} valid, {int(amb.sum())} in the guard band), "
         f"{ns} shots equal ({int((~oks).sum())} flagged), planner {found_n}/{nq} found, {differ} differ after a guard-band decision")
 

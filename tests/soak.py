@@ -212,4 +212,48 @@ for r in range(rounds):
     say(f"config {r} ({desc}): rollouts of {n} parents equal ({int(v.sum())} valid, {int(amb.sum())} in the guard band), "
         f"{ns} shots equal ({int((~oks).sum())} flagged), planner {found_n}/{nq} found, {differ} differ after a guard-band decision")
 
+# ---- obstacle raster + heuristic from point lists, grid A*, Reeds-Shepp trajectories
+import test_gpu_astar as TA  # noqa: E402
+import test_gpu_heuristic as TH  # noqa: E402
+for r in range(rounds):
+    seed = 0xBEE70000 + 431 * r
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(100, 900))
+    ex, ey = float(rng.uniform(40, 140)), float(rng.uniform(40, 140))
+    lo = float(rng.choice([0.0, -30.0, 25.0]))
+    ox, oy = rng.uniform(lo, lo + ex, n), rng.uniform(lo, lo + ey, n)
+    if r % 2:
+        ox, oy = np.round(ox), np.round(oy)  # on the lattice
+    ox[:4], oy[:4] = [lo, lo + ex, lo, lo + ex], [lo, lo, lo + ey, lo + ey]
+    reso = float(rng.choice([0.5, 1.0, 2.0, 2.5]))
+    rr = float(rng.choice([0.3, 0.5, 1.0, 1.7])) * reso
+    m = api.ObstacleMap(ctx, ox, oy)
+    obs, dims = api.calc_obsmap(ctx, m, reso, rr)
+    st, eobs, edims = O.obsmap(ox, oy, reso, rr, 1)
+    assert dims.tolist() == edims.tolist() and (obs == eobs).all()
+    gx, gy = float(rng.uniform(lo + 5, lo + ex - 5)), float(rng.uniform(lo + 5, lo + ey - 5))
+    hm, _ = api.calc_holonomic_heuristic_with_obstacle(ctx, m, gx, gy, reso, rr)
+    st, exp, _ = O.heuristic(ox, oy, gx, gy, reso, rr)
+    assert st == 0
+    TH.same_grid(hm, exp)
+    paths = 0
+    for _ in range(4):
+        s_ = [float(rng.uniform(lo + 2, lo + ex - 2)), float(rng.uniform(lo + 2, lo + ey - 2))]
+        g_ = [float(rng.uniform(lo + 2, lo + ex - 2)), float(rng.uniform(lo + 2, lo + ey - 2))]
+        paths += TA.same(ctx, m, ox, oy, s_, g_, reso, rr) is not None
+    # trajectories of every word of a few pairs
+    maxc = float(rng.choice([0.05, 0.1, 0.1955, 0.4]))
+    step = float(rng.choice([0.1, 0.2, 0.4, 1.0]))
+    for _ in range(6):
+        q0 = [float(rng.uniform(0, 60)), float(rng.uniform(0, 60)), float(rng.uniform(-7, 7))]
+        q1 = [float(rng.uniform(0, 60)), float(rng.uniform(0, 60)), float(rng.uniform(-7, 7))]
+        npth, bidx, words, flags = api.rs_batch(ctx, [q0], [q1], maxc)
+        if flags[0] & 2:
+            continue
+        got = api.calc_all_paths(ctx, *q0, *q1, maxc, step)
+        st, exp_paths = O.rs_all_paths(q0, q1, maxc, step)
+        TR.check_same_paths(got, exp_paths)
+    say(f"lists {r}: raster {dims.tolist()[4:]} reso {reso} rr {rr:.2f} equal, heuristic equal, grid A* {paths}/4 paths equal, "
+        f"trajectories at maxc {maxc} step {step} equal")
+
 say("soak done")

@@ -256,4 +256,42 @@ for r in range(rounds):
     say(f"lists {r}: raster {dims.tolist()[4:]} reso {reso} rr {rr:.2f} equal, heuristic equal, grid A* {paths}/4 paths equal, "
         f"trajectories at maxc {maxc} step {step} equal")
 
+# ---- large planner batches (two lanes, device-side tables of known cells) under drawn Configs
+from concurrent.futures import ThreadPoolExecutor  # noqa: E402
+for r in range(max(1, rounds // 10)):
+    seed = 0xB16B0000 + 211 * r
+    rng = np.random.default_rng(seed)
+    conf = A.demo_config()
+    conf.xy_reso = float(rng.choice([1.5, 2.0]))
+    conf.yaw_reso = math.radians(float(rng.choice([10.0, 15.0])))
+    conf.n_steer = int(rng.choice([10, 20]))
+    conf.h_cost = float(rng.choice([5.0, 15.0]))
+    msz = 320
+    occ = W.plan_map(msz, 0.02, seed=seed + 1)
+    ox, oy = W.raster_to_points(occ)
+    m = api.ObstacleMap(ctx, raster=occ)
+    om = O.OracleMap(ox, oy)
+    nq = 1200
+    cand_s = np.c_[rng.uniform(10, msz - 10, 3 * nq), rng.uniform(10, msz - 10, 3 * nq), rng.uniform(-3, 3, 3 * nq)]
+    free = api.collision_flags(ctx, m, conf, cand_s[:, 0], cand_s[:, 1], cand_s[:, 2]) == 0
+    starts = cand_s[free][:nq]
+    gp = np.c_[rng.uniform(20, msz - 20, 40), rng.uniform(20, msz - 20, 40), rng.uniform(-3, 3, 40)]
+    gp = gp[api.collision_flags(ctx, m, conf, gp[:, 0], gp[:, 1], gp[:, 2]) == 0][:6]
+    goals = gp[rng.integers(0, len(gp), len(starts))]
+    cap = 500
+    ctx.set_max_expansions(cap)
+    O.set_max_expansions(cap)
+    try:
+        res = api.plan_batch(ctx, m, conf, starts, goals, cap=30000, closed_cap=cap)
+        with ThreadPoolExecutor(8) as ex:
+            exp_all = list(ex.map(lambda i: om.plan(conf, starts[i], goals[i]), range(len(starts))))
+        differ = sum(not TP.same_batch_query(res, i, e, cap) for i, e in enumerate(exp_all))
+    finally:
+        ctx.set_max_expansions(100000)
+        O.set_max_expansions(0)
+    exs = np.array([int(res["stats"][i].expansions) for i in range(len(starts))])
+    say(f"big batch {r}: {len(starts)} queries on a {msz}^2 map (xy {conf.xy_reso}, n_steer {conf.n_steer}): "
+        f"{int((res['status'] == 0).sum())} found, {int((exs >= cap).sum())} at the cap, median {int(np.median(exs))} closed, "
+        f"{differ} differ after a guard-band decision")
+
 say("soak done")

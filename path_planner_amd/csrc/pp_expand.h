@@ -39,6 +39,7 @@ struct PpExpandDev {
   // optional, instead of hmaps: the grids as the relaxation leaves them, in its blocked working
   // layout (pp_blocked_value); grid p occupies stored columns p * hblk_plane_cols onwards
   const double* hblk = nullptr;
+  const uint32_t* hblk_stamp = nullptr;  // per 32x32 block: 0 = never written, all +inf
   uint32_t hblk_nty = 0;
   uint64_t hblk_plane_cols = 0;
   // optional: entries of primitives that are not valid keep whatever the arrays held (only the

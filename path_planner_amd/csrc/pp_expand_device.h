@@ -17,10 +17,13 @@ __device__ __forceinline__ void pp_turn(double& c, double& s, double cd, double 
 // of 1024 doubles, block (x >> 5, y >> 5) at index (x >> 5) * nty + (y >> 5); inside a block the
 // 4x4 patch of cells (x & 3, y & 3) belongs to lane ((x & 31) >> 2) * 8 + ((y & 31) >> 2), cells
 // 2m, 2m+1 of a lane are adjacent and the 64 lanes of a pair consecutive (blk_off in
-// pp_heuristic.hip, which owns the layout).
-__device__ __forceinline__ double pp_blocked_value(const double* __restrict__ blk, uint32_t nty, uint64_t x,
+// pp_heuristic.hip, which owns the layout).  stamp[t] == 0 marks a block the relaxation never
+// wrote: its memory is uninitialised and every cell of it is +inf.
+__device__ __forceinline__ double pp_blocked_value(const double* __restrict__ blk,
+                                                   const uint32_t* __restrict__ stamp, uint32_t nty, uint64_t x,
                                                    uint64_t y) {
   const uint64_t t = (x >> 5) * nty + (y >> 5);
+  if (stamp[t] == 0u) return __longlong_as_double(0x7FF0000000000000ll);
   const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
   const uint32_t k = (lx & 3u) * 4u + (ly & 3u), lane = (lx >> 2) * 8u + (ly >> 2);
   return blk[t * 1024u + ((k >> 1) * 64u + lane) * 2u + (k & 1u)];
@@ -143,7 +146,7 @@ __device__ __forceinline__ void pp_expand_item(uint64_t t, uint32_t n_prim, cons
       // is_index_ok guarantees minx < xind < maxx, so the lookup is inside the grid
       uint64_t hx = xind - prm.minx, hy = yind - prm.miny;
       if (hx < out.hxw && hy < out.hyw) {
-        const double h = out.hblk ? pp_blocked_value(out.hblk, out.hblk_nty,
+        const double h = out.hblk ? pp_blocked_value(out.hblk, out.hblk_stamp, out.hblk_nty,
                                                      (uint64_t)out.hmap_id[p] * out.hblk_plane_cols + hx, hy)
                                   : out.hmaps[out.hmap_id[p]][hx * out.hyw + hy];
         fc = cost + out.h_cost * h;

@@ -170,9 +170,19 @@ struct TileGrid {
                          // kept current for the rows on a scheduling tile's edge (even block rows: s = 0, odd: s = 1).
                          // In the block itself the 32 cells of such a row sit in 32 different cache lines;
                          // the tiles above and below read them from here
+  uint32_t* stamp;       // stamp[t]: 0 = block t has not been written yet: every cell of it is +inf and neither its
+                         // costs nor its row copies are initialised memory; 1 = written before the rounds; r + 2 =
+                         // first written by round r.  A round treats a block first written in the same launch
+                         // as still unwritten (+inf is what the block held when the round began), so it never
+                         // reads a block that is half way through its first write
   uint32_t ntx, nty;     // 32x32 blocks over the stored columns
   uint32_t nsx, nsy;     // scheduling tiles: 2x2 blocks = 64x64 cells, one workgroup each
 };
+constexpr uint32_t kAfterRounds = 0xFFFFFFF0u;  // "round" for readers that run when no round is in flight
+__device__ inline bool tile_block_live(const TileGrid& g, uint32_t t, uint32_t round) {
+  const uint32_t s = g.stamp[t];
+  return s != 0u && s <= round + 1u;
+}
 
 struct TileWork {
   uint32_t* list;        // tiles to relax this round
@@ -215,12 +225,14 @@ __device__ inline double tile_cell_value(const TileGrid& g, int64_t x, int64_t y
     return __longlong_as_double((long long)kInfBits);
   const uint32_t t = (uint32_t)(x >> 5) * g.nty + (uint32_t)(y >> 5);
   const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
+  if (!tile_block_live(g, t, kAfterRounds)) return __longlong_as_double((long long)kInfBits);
   return g.blk[(uint64_t)t * kBlk + blk_off((lx & 3u) * 4u + (ly & 3u), (lx >> 2) * 8u + (ly >> 2))];
 }
 
 // The same, and whether a visit of the cell's own tile could lower it (neither blocked nor a
 // source-only cell, inside the grid).
-__device__ inline double tile_cell_value(const TileGrid& g, int64_t x, int64_t y, bool& relaxable) {
+__device__ inline double tile_cell_value(const TileGrid& g, int64_t x, int64_t y, bool& relaxable,
+                                         uint32_t round) {
   relaxable = false;
   if (x < 0 || y < 0 || x >= (int64_t)g.ntx * kTile || y >= (int64_t)g.nty * kTile)
     return __longlong_as_double((long long)kInfBits);
@@ -228,6 +240,7 @@ __device__ inline double tile_cell_value(const TileGrid& g, int64_t x, int64_t y
   const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
   const uint32_t k = (lx & 3u) * 4u + (ly & 3u), ln = (lx >> 2) * 8u + (ly >> 2);
   relaxable = ((g.mask[(uint64_t)t * 64 + ln] >> k) & 0x10001u) == 0u;
+  if (!tile_block_live(g, t, round)) return __longlong_as_double((long long)kInfBits);
   return g.blk[(uint64_t)t * kBlk + blk_off(k, ln)];
 }
 
@@ -237,7 +250,8 @@ __device__ inline void tile_yrim_store(const TileGrid& g, uint32_t t, uint32_t l
   if (ly == 31u) g.yrim[((uint64_t)t * 2 + 1) * 32 + lx] = v;
 }
 // tile_cell_value for a cell of such a row, read from the copy.
-__device__ inline double tile_yrim_value(const TileGrid& g, int64_t x, int64_t y, bool& relaxable) {
+__device__ inline double tile_yrim_value(const TileGrid& g, int64_t x, int64_t y, bool& relaxable,
+                                         uint32_t round) {
   relaxable = false;
   if (x < 0 || y < 0 || x >= (int64_t)g.ntx * kTile || y >= (int64_t)g.nty * kTile)
     return __longlong_as_double((long long)kInfBits);
@@ -245,6 +259,7 @@ __device__ inline double tile_yrim_value(const TileGrid& g, int64_t x, int64_t y
   const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
   const uint32_t k = (lx & 3u) * 4u + (ly & 3u), ln = (lx >> 2) * 8u + (ly >> 2);
   relaxable = ((g.mask[(uint64_t)t * 64 + ln] >> k) & 0x10001u) == 0u;
+  if (!tile_block_live(g, t, round)) return __longlong_as_double((long long)kInfBits);
   return g.yrim[((uint64_t)t * 2 + (ly ? 1u : 0u)) * 32 + lx];
 }
 
@@ -252,6 +267,9 @@ __device__ inline double tile_yrim_value(const TileGrid& g, int64_t x, int64_t y
 // the strided rows of the dense arrays are read in long runs.  A lane's patch is four runs of four
 // consecutive cells of a dense column: a run that lies inside the grid and is suitably aligned is
 // moved in one piece (a dword of the raster, two 16-byte pieces of the costs).
+// With init_inf the costs all start at +inf, and a block of +inf is not written at all: its stamp
+// says so and the first visit that moves one of its cells writes it whole.  Blocks that hold
+// another rank's columns are the exception (the halo intake compares against their cells).
 __global__ void __launch_bounds__(256)
 k_tile_pack(DenseView d, TileGrid g, uint32_t ntiles, int init_inf) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -260,6 +278,8 @@ k_tile_pack(DenseView d, TileGrid g, uint32_t ntiles, int init_inf) {
   for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * 4) {
     const uint32_t tx = t / g.nty, ty = t - tx * g.nty;
     const int64_t y0 = (int64_t)ty * kTile + 4 * py;
+    const uint64_t bx0 = (uint64_t)tx * kTile, bx1 = std::min<uint64_t>(bx0 + kTile, d.ncols);
+    const bool eager = !init_inf || bx0 < d.own_lo || bx1 > d.own_hi;
     uint32_t m = 0;
     double v[16];
 #pragma unroll
@@ -319,11 +339,13 @@ k_tile_pack(DenseView d, TileGrid g, uint32_t ntiles, int init_inf) {
         }
       }
     }
+    g.mask[(uint64_t)t * 64 + lane] = m;
+    if (lane == 0u) g.stamp[t] = eager ? 1u : 0u;
+    if (!eager) continue;
     double* b = g.blk + (uint64_t)t * kBlk;
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2)
       *(double2*)(b + blk_off(2 * k2, lane)) = make_double2(v[2 * k2], v[2 * k2 + 1]);
-    g.mask[(uint64_t)t * 64 + lane] = m;
     if (py == 0u || py == 7u) {  // the block's first / last row
       double* yr = g.yrim + ((uint64_t)t * 2 + (py ? 1u : 0u)) * 32 + 4 * px;
       const int j = py ? 3 : 0;
@@ -341,10 +363,12 @@ __global__ void __launch_bounds__(256) k_tile_unpack(DenseView d, TileGrid g, ui
     const uint32_t tx = t / g.nty, ty = t - tx * g.nty;
     const int64_t y0 = (int64_t)ty * kTile + 4 * py;
     const double* b = g.blk + (uint64_t)t * kBlk;
+    const bool live = g.stamp[t] != 0u;  // a block nobody wrote is +inf throughout
     double v[16];
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) {
-      const double2 p = *(const double2*)(b + blk_off(2 * k2, lane));
+      double2 p = make_double2(__longlong_as_double((long long)kInfBits), __longlong_as_double((long long)kInfBits));
+      if (live) p = *(const double2*)(b + blk_off(2 * k2, lane));
       v[2 * k2] = p.x;
       v[2 * k2 + 1] = p.y;
     }
@@ -547,10 +571,13 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
     // a cell that is only a source.
     double e[6][6], floor_[4][4];
     const uint32_t m = have ? g.mask[(uint64_t)blk_id * 64 + lane] : 0xFFFFu;
+    // a block no visit has written yet is +inf throughout (its stamp cannot be this round's: a tile
+    // is listed once per round)
+    const bool fresh = have && g.stamp[blk_id] == 0u;
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) {
       double2 p = make_double2(INF, INF);
-      if (have) p = *(const double2*)(blk + blk_off(2 * k2, lane));
+      if (have && !fresh) p = *(const double2*)(blk + blk_off(2 * k2, lane));
       e[(2 * k2) / 4 + 1][(2 * k2) % 4 + 1] = p.x;
       e[(2 * k2 + 1) / 4 + 1][(2 * k2 + 1) % 4 + 1] = p.y;
     }
@@ -570,7 +597,7 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
         const int side = r >= kSTile + 2, o = (side ? r - (kSTile + 2) : r) - 1;  // o = -1 .. 64
         const int q = (o + 4) >> 2, j = (o + 4) & 3;
         bool rel;
-        const double v = tile_cell_value(g, side ? X0 + kSTile : X0 - 1, Y0 + o, rel);
+        const double v = tile_cell_value(g, side ? X0 + kSTile : X0 - 1, Y0 + o, rel, round);
         if (!side)
           lds[(4 + j) * kSSlot + 0 * kSRow + q] = v;                // slot (3, j)
         else
@@ -586,7 +613,7 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
         const int prow = (o >> 2) + 1, i = o & 3;
         const int s3 = i == 0 ? 3 : (i == 3 ? 7 : 9 + i), s0 = i == 0 ? 0 : (i == 3 ? 4 : 7 + i);
         bool rel;
-        const double v = tile_yrim_value(g, X0 + o, side ? Y0 + kSTile : Y0 - 1, rel);
+        const double v = tile_yrim_value(g, X0 + o, side ? Y0 + kSTile : Y0 - 1, rel, round);
         if (!side)
           lds[s3 * kSSlot + prow * kSRow + 0] = v;                  // slot (i, 3)
         else
@@ -697,12 +724,19 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
     // written): all sixteen count as moved.  For the wake test below an edge cell that did not
     // change can only repeat a wake its neighbour has had already -- if the neighbour has relaxed
     // since, its cells are low enough for the test to say no.
-    const bool wrote = have && moved_any;
+    // A block written for the first time is written whole, the patches still at +inf included,
+    // and stamped; it stays unwritten when none of its cells moved.
+    const bool moved_here = have && moved_any;
+    const bool first_write = fresh && __ballot(moved_here) != 0ull;
+    const bool wrote = moved_here || first_write;
     if (wrote) {
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2)
         *(double2*)(blk + blk_off(2 * k2, lane)) =
             make_double2(e[(2 * k2) / 4 + 1][(2 * k2) % 4 + 1], e[(2 * k2 + 1) / 4 + 1][(2 * k2 + 1) % 4 + 1]);
+    }
+    if (first_write && lane == 0u) g.stamp[blk_id] = round + 2u;
+    if (moved_here) {
       // a slab's first / last owned column (reported to the caller) runs through this patch
       const uint64_t c0 = (uint64_t)(X0 + qx * kTile + 4 * px);
       if (w.own_first >= c0 && w.own_first < c0 + 4) atomicOr(&edge_bits, 256u);
@@ -721,16 +755,16 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
       *(double2*)(yr + 2) = make_double2(e[3][4], e[4][4]);
     }
     // moved cells on the tile's edge: which neighbours can they still reach
-    if (__ballot(wrote) != 0ull) {
+    if (__ballot(moved_here) != 0ull) {
       if (qx == 0) {
-        if (px == 0 && wrote) edge_reach<0>(e, reach, qy * kTile + 4 * py - 1, diag, wake_key);
+        if (px == 0 && moved_here) edge_reach<0>(e, reach, qy * kTile + 4 * py - 1, diag, wake_key);
       } else {
-        if (px == kPps - 1 && wrote) edge_reach<1>(e, reach, qy * kTile + 4 * py - 1, diag, wake_key);
+        if (px == kPps - 1 && moved_here) edge_reach<1>(e, reach, qy * kTile + 4 * py - 1, diag, wake_key);
       }
       if (qy == 0) {
-        if (py == 0 && wrote) edge_reach<2>(e, reach, qx * kTile + 4 * px - 1, diag, wake_key);
+        if (py == 0 && moved_here) edge_reach<2>(e, reach, qx * kTile + 4 * px - 1, diag, wake_key);
       } else {
-        if (py == kPps - 1 && wrote) edge_reach<3>(e, reach, qx * kTile + 4 * px - 1, diag, wake_key);
+        if (py == kPps - 1 && moved_here) edge_reach<3>(e, reach, qx * kTile + 4 * px - 1, diag, wake_key);
       }
     }
     __syncthreads();
@@ -786,12 +820,31 @@ __global__ void k_fill_inf(double* p, uint64_t n) {
     p[i] = __longlong_as_double((long long)kInfBits);
 }
 
+// Goal cells are stored before the rounds, so their blocks have to hold real values by then: one
+// wave per goal writes +inf over a block that is still unwritten.  The stamps are left alone (two
+// goals of neighbouring planes may share a block; both waves then write the same values) and are
+// set by the seeding kernel that follows.  goals == nullptr: the one goal (sx, sy).
+__global__ void __launch_bounds__(64)
+k_seed_fill(TileGrid g, uint32_t n, uint64_t plane_cols, const int64_t* __restrict__ goals, int64_t sx, int64_t sy) {
+  const uint32_t p = blockIdx.x, lane = threadIdx.x;
+  if (p >= n) return;
+  const int64_t x = goals ? (int64_t)(p * plane_cols) + goals[2 * p] : sx, y = goals ? goals[2 * p + 1] : sy;
+  const uint32_t t = (uint32_t)(x >> 5) * g.nty + (uint32_t)(y >> 5);
+  if (g.stamp[t] != 0u) return;
+  const double INF = __longlong_as_double((long long)kInfBits);
+  double* b = g.blk + (uint64_t)t * kBlk;
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) *(double2*)(b + blk_off(2 * k2, lane)) = make_double2(INF, INF);
+  g.yrim[(uint64_t)t * 64 + lane] = INF;  // both row copies
+}
+
 // The goal is inserted without check_node (astar.rs:155): cost 0 even on an obstacle or border.
 __global__ void k_seed_goal(TileGrid g, TileWork w, int64_t x, int64_t y) {
   const uint32_t t = (uint32_t)(x >> 5) * g.nty + (uint32_t)(y >> 5);
   const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
   g.blk[(uint64_t)t * kBlk + blk_off((lx & 3u) * 4u + (ly & 3u), (lx >> 2) * 8u + (ly >> 2))] = 0.0;
   tile_yrim_store(g, t, lx, ly, 0.0);
+  g.stamp[t] = 1u;
   tile_wake(g, w, x >> 6, y >> 6, 0ull);
   atomicMin(&w.minkey[0], 0ull);
 }
@@ -805,6 +858,7 @@ __global__ void k_seed_goals(TileGrid g, TileWork w, uint32_t planes, uint64_t p
   const uint32_t lx = (uint32_t)x & 31u, ly = (uint32_t)y & 31u;
   g.blk[(uint64_t)t * kBlk + blk_off((lx & 3u) * 4u + (ly & 3u), (lx >> 2) * 8u + (ly >> 2))] = 0.0;
   tile_yrim_store(g, t, lx, ly, 0.0);
+  g.stamp[t] = 1u;
   tile_wake(g, w, x >> 6, y >> 6, 0ull);
   if (p == 0) atomicMin(&w.minkey[0], 0ull);
 }
@@ -929,9 +983,9 @@ int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run, void** own_b
   if (nblocks == 0 || nblocks >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t b_blk = al(nblocks * kBlk * 8), b_mask = al(nblocks * 64 * 4), b_list = al(ntiles * 4);
-  const size_t b_yrim = al(nblocks * 2 * 32 * 8);
+  const size_t b_yrim = al(nblocks * 2 * 32 * 8), b_stamp = al(nblocks * 4);
   const size_t b_bits = al(((ntiles + 63) / 64) * 8), b_key = al(ntiles * 8), b_misc = 256;
-  const size_t need = b_blk + b_mask + b_yrim + b_list + b_bits + b_key + b_misc;
+  const size_t need = b_blk + b_mask + b_yrim + b_stamp + b_list + b_bits + b_key + b_misc;
   if (need > wbytes) {
     if (wbuf) PP_HIP(ctx, hipFree(wbuf));
     wbuf = nullptr;
@@ -946,6 +1000,8 @@ int32_t tile_prepare(pp_ctx* ctx, const DenseView& d, TileRun* run, void** own_b
   b += b_mask;
   run->g.yrim = (double*)b;
   b += b_yrim;
+  run->g.stamp = (uint32_t*)b;
+  b += b_stamp;
   run->g.ntx = (uint32_t)ntx;
   run->g.nty = (uint32_t)nty;
   run->g.nsx = (uint32_t)nsx;
@@ -1068,6 +1124,8 @@ extern "C" int32_t pp_wavefront_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const
   if (st != PP_OK) return st;
   const unsigned sg = tile_stream_grid(ctx, run.nblocks);
   hipLaunchKernelGGL(k_tile_pack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks, 1);
+  hipLaunchKernelGGL(k_seed_fill, dim3(1), dim3(64), 0, ctx->stream, run.g, 1u, (uint64_t)0, (const int64_t*)nullptr,
+                     (int64_t)goal_x, (int64_t)goal_y);
   hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, run.g, run.w, (int64_t)goal_x,
                      (int64_t)goal_y);
   uint32_t status[4];
@@ -1146,6 +1204,8 @@ int32_t pp_wavefront_multi_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint
     if (bound) run.w.limit = limit;
     const unsigned sg = tile_stream_grid(ctx, run.nblocks);
     hipLaunchKernelGGL(k_tile_pack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks, 1);
+    hipLaunchKernelGGL(k_seed_fill, dim3(np), dim3(64), 0, ctx->stream, run.g, np, xw + 1, (const int64_t*)d_goals,
+                       (int64_t)0, (int64_t)0);
     hipLaunchKernelGGL(k_seed_goals, dim3((np + 63) / 64), dim3(64), 0, ctx->stream, run.g, run.w, np,
                        xw + 1, (const int64_t*)d_goals);
     uint32_t status[4];
@@ -1154,7 +1214,7 @@ int32_t pp_wavefront_multi_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, const uint
     if (!keep_blocked)
       hipLaunchKernelGGL(k_tile_unpack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks);
     else
-      *keep_blocked = PpBlockedGrids{run.g.blk, run.g.nty, xw + 1};
+      *keep_blocked = PpBlockedGrids{run.g.blk, run.g.stamp, run.g.nty, xw + 1};
     PP_HIP(ctx, hipGetLastError());
     PP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // d_goals is reused by the next pass
     if (bound) {
@@ -1190,7 +1250,7 @@ extern "C" int32_t pp_wavefront_slab_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, 
                        run.g, run.w, d_halo_lo_new, d_halo_hi_new);
   const unsigned sg = tile_stream_grid(ctx, run.nblocks);
   hipLaunchKernelGGL(k_tile_pack, dim3(sg), dim3(256), 0, ctx->stream, d, run.g, run.nblocks, 0);
-  if (seed_goal && goal_owned)
+  if (seed_goal && goal_owned)  // this entry point packs every block with the caller's values
     hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, run.g, run.w, d.goal_x, d.goal_y);
   uint32_t status[4] = {0, 0, 0, 0};
   st = tile_run(ctx, run, iters, status);
@@ -1255,8 +1315,11 @@ extern "C" int32_t pp_slab_reset(pp_slab* s, const uint8_t* d_obs_slab) {
   s->moved_min = (unsigned long long*)((char*)s->run.w.count + 192);
   s->sg = tile_stream_grid(ctx, s->run.nblocks);
   hipLaunchKernelGGL(k_tile_pack, dim3(s->sg), dim3(256), 0, ctx->stream, s->d, s->run.g, s->run.nblocks, 1);
-  if (s->d.goal_x >= 0)
+  if (s->d.goal_x >= 0) {
+    hipLaunchKernelGGL(k_seed_fill, dim3(1), dim3(64), 0, ctx->stream, s->run.g, 1u, (uint64_t)0,
+                       (const int64_t*)nullptr, s->d.goal_x, s->d.goal_y);
     hipLaunchKernelGGL(k_seed_goal, dim3(1), dim3(1), 0, ctx->stream, s->run.g, s->run.w, s->d.goal_x, s->d.goal_y);
+  }
   PP_HIP(ctx, hipGetLastError());
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the raster may be released after the call
   return PP_OK;

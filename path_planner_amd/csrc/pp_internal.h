@@ -135,6 +135,7 @@ int32_t pp_wavefront_multi_finish(pp_ctx* ctx);
 // layout instead of writing the dense arrays (valid until the context's next relaxation).
 struct PpBlockedGrids {
   const double* blk = nullptr;
+  const uint32_t* stamp = nullptr;  // per block: 0 = never written (its cells are +inf, its memory is not initialised)
   uint32_t nty = 0;
   uint64_t plane_cols = 0;
 };

@@ -418,7 +418,7 @@ __global__ void k_gather_blocked(uint32_t n, PpBlockedGrids g, uint64_t hyw, con
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const uint64_t hx = off[i] / hyw, hy = off[i] - hx * hyw;
-    out[i] = pp_blocked_value(g.blk, g.nty, (uint64_t)slot[i] * g.plane_cols + hx, hy);
+    out[i] = pp_blocked_value(g.blk, g.stamp, g.nty, (uint64_t)slot[i] * g.plane_cols + hx, hy);
   }
 }
 
@@ -694,6 +694,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   eo.hmaps = (const double* const*)tab_buf.p;
   if (keep_blocked) {
     eo.hblk = blocked.blk;
+    eo.hblk_stamp = blocked.stamp;
     eo.hblk_nty = blocked.nty;
     eo.hblk_plane_cols = blocked.plane_cols;
   }

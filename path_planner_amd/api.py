@@ -59,6 +59,15 @@ class Context:
         """Worker threads plan_batch may start beside the calling thread (default 15)."""
         _chk(self.lib.pp_ctx_set_host_threads(self.h, int(n)), "pp_ctx_set_host_threads")
 
+    def set_table_budget(self, nbytes):
+        """Device memory plan_batch may take for its per-query tables of known cells (default 16 GiB,
+        0 = no tables); the plans do not depend on it."""
+        _chk(self.lib.pp_ctx_set_table_budget(self.h, int(nbytes)), "pp_ctx_set_table_budget")
+
+    def device_bytes(self):
+        """Device memory the context holds in its grown-on-demand buffers."""
+        return int(self.lib.pp_ctx_device_bytes(self.h))
+
     def synchronize(self):
         _chk(self.lib.pp_ctx_synchronize(self.h), "pp_ctx_synchronize")
 

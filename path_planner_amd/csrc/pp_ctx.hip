@@ -54,6 +54,7 @@ extern "C" void pp_ctx_destroy(pp_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->slabs && ctx->slabs_orphan) ctx->slabs_orphan(ctx);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->wave_resume && ctx->wave_resume_free) ctx->wave_resume_free(ctx->wave_resume);
   if (ctx->wave_buf) (void)hipFree(ctx->wave_buf);
@@ -100,10 +101,28 @@ extern "C" int32_t pp_ctx_set_heuristic_workspace(pp_ctx* ctx, uint64_t bytes) {
   return PP_OK;
 }
 
+extern "C" int32_t pp_ctx_set_table_budget(pp_ctx* ctx, uint64_t bytes) {
+  if (!ctx) return PP_ERR_INVALID;
+  ctx->ftab_budget = (size_t)bytes;
+  if (ctx->ftab_buf && ctx->ftab_bytes > ctx->ftab_budget) {  // give back what no longer fits
+    (void)hipSetDevice(ctx->device);
+    PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PP_HIP(ctx, hipFree(ctx->ftab_buf));
+    ctx->ftab_buf = nullptr;
+    ctx->ftab_bytes = 0;
+  }
+  return PP_OK;
+}
+
 extern "C" int32_t pp_ctx_set_host_threads(pp_ctx* ctx, uint32_t n) {
   if (!ctx) return PP_ERR_INVALID;
   ctx->host_threads = std::min<uint32_t>(n, 255);
   return PP_OK;
+}
+
+extern "C" uint64_t pp_ctx_device_bytes(const pp_ctx* ctx) {
+  if (!ctx) return 0;
+  return (uint64_t)ctx->scratch_bytes + ctx->wave_bytes + ctx->ftab_bytes + ctx->plan_bytes + ctx->hmap_bytes;
 }
 
 extern "C" int32_t pp_last_hip_error(pp_ctx* ctx) { return ctx ? ctx->last_hip_error : 0; }

@@ -400,6 +400,9 @@ __global__ void __launch_bounds__(256) k_tile_unpack(DenseView d, TileGrid g, ui
 // kListThreads: 1024 for large grids (fewer atomics in the crowded rounds: 16384^2 20.1 -> 19.3 ms),
 // 256 for small ones, whose rounds are short and pay for the wider workgroup's barriers instead
 // (4096^2: 3.38 against 3.44 ms).
+#ifdef PP_LAB_TRACE
+__device__ double lab_trace[8192][2];  // per round: lowest pending key, tiles listed
+#endif
 template <int kListThreads>
 __global__ void __launch_bounds__(kListThreads) k_tile_list(TileGrid g, TileWork w, uint32_t round) {
   // one list-space reservation and one waiting-key minimum per workgroup: the atomics of a crowded
@@ -412,6 +415,12 @@ __global__ void __launch_bounds__(kListThreads) k_tile_list(TileGrid g, TileWork
   if (t == 0) {
     w.count[(round + 1) % 3] = 0;
     w.minkey[(round + 2) % 3] = kInfBits;
+#ifdef PP_LAB_TRACE
+    if (round < 8192) {
+      lab_trace[round][0] = __longlong_as_double((long long)w.minkey[round % 3]);
+      if (round > 0) lab_trace[round - 1][1] = (double)w.count[(round + 2) % 3];
+    }
+#endif
   }
   // the key is fetched alongside the bitmap word, not after it: a round waits for this kernel
   const uint32_t word = t < w.ntiles ? w.bitmap[t >> 5] : 0u;
@@ -636,6 +645,7 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
     for (;;) {
       const bool active = (todo >> wv) & 1u;
       const uint32_t nxt = (sweeps + 1u) % 3u;
+      bool moved = false;  // values only ever go down
       if (tid == 0) act[(sweeps + 2u) % 3u] = 0;  // last read before the previous barrier, filled after the next
       if (active) {
 #pragma unroll
@@ -648,7 +658,6 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
             e[ii][jj] = lds[rim_slot(si, sj) * kSSlot + own_slot + dx * kSRow + dy];
           }
         }
-        bool moved = false;  // values only ever go down
 #pragma unroll
         for (int i = 1; i <= 4; ++i) {
 #pragma unroll
@@ -703,13 +712,15 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
         // A front that winds through the tile needs many sweeps, and the round lasts as long as
         // its slowest tile.  Such a tile stops here and wakes itself, with the lowest value of the
         // waves that still had work as its key, so the round ends and the rest of the front moves
-        // on (4096^2: 4.3 -> 3.7 ms, 16384^2: 27.4 -> 26.7 ms)
+        // on (4096^2: 4.3 -> 3.7 ms, 16384^2: 27.4 -> 26.7 ms).  (Keying the tile by the patches that
+        // moved in the last sweep alone, a tighter bound, changes neither the rounds nor the time.)
         double mv = INF;
+        if ((todo >> wv) & 1u) {
 #pragma unroll
-        for (int i = 1; i <= 4; ++i)
+          for (int i = 1; i <= 4; ++i)
 #pragma unroll
-          for (int j = 1; j <= 4; ++j) mv = pp_min_f64(mv, e[i][j]);
-        if (!((todo >> wv) & 1u)) mv = INF;
+            for (int j = 1; j <= 4; ++j) mv = pp_min_f64(mv, e[i][j]);
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) mv = pp_min_f64(mv, __shfl_xor(mv, off));
         if (lane == 0 && mv < INF) atomicMin(&self_key, (unsigned long long)__double_as_longlong(mv));
@@ -1079,6 +1090,14 @@ int32_t tile_run(pp_ctx* ctx, TileRun& run, uint64_t* rounds_out, uint32_t statu
   PP_HIP(ctx, hipGetLastError());
   PP_HIP(ctx, hipMemcpyAsync(status_out, run.w.status, 16, hipMemcpyDeviceToHost, ctx->stream));
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+#ifdef PP_LAB_TRACE
+  {
+    static double tr[8192][2];
+    PP_HIP(ctx, hipMemcpyFromSymbol(tr, HIP_SYMBOL(lab_trace), sizeof(tr)));
+    for (uint32_t r = 0; r < round && r < 8192; ++r)
+      fprintf(stderr, "[trace] round %u minkey %.1f listed %.0f\n", r, tr[r][0], tr[r][1]);
+  }
+#endif
 #ifdef PP_LAB_PHASES
   {
     unsigned long long prof[3];
@@ -1268,7 +1287,8 @@ extern "C" int32_t pp_wavefront_slab_dev(pp_ctx* ctx, uint64_t xw, uint64_t yw, 
 // packed once, every pp_slab_relax continues from the state the last one left, and the dense costs
 // are written only when asked for.
 struct pp_slab {
-  pp_ctx* ctx = nullptr;
+  pp_ctx* ctx = nullptr;                    // null once the context is gone: every call then fails, destroy still works
+  pp_slab *prev = nullptr, *next = nullptr;  // the context's list of live sessions
   TileRun run;
   DenseView d{};
   unsigned sg = 0;
@@ -1278,6 +1298,21 @@ struct pp_slab {
 };
 
 extern "C" int32_t pp_slab_reset(pp_slab* s, const uint8_t* d_obs_slab);
+
+// A context that is destroyed before its slab sessions takes their device memory with it; the
+// handles stay valid for pp_slab_destroy and refuse everything else.
+static void slabs_orphan(pp_ctx* ctx) {
+  for (pp_slab* s = (pp_slab*)ctx->slabs; s;) {
+    pp_slab* nx = s->next;
+    if (s->buf) (void)hipFree(s->buf);
+    s->buf = nullptr;
+    s->bytes = 0;
+    s->ctx = nullptr;
+    s->prev = s->next = nullptr;
+    s = nx;
+  }
+  ctx->slabs = nullptr;
+}
 
 extern "C" int32_t pp_slab_create(pp_ctx* ctx, uint64_t xw, uint64_t yw, uint64_t x_begin, uint64_t x_end,
                                   const uint8_t* d_obs_slab, uint64_t goal_x, uint64_t goal_y, pp_slab** out) {
@@ -1300,12 +1335,16 @@ extern "C" int32_t pp_slab_create(pp_ctx* ctx, uint64_t xw, uint64_t yw, uint64_
     delete s;
     return st;
   }
+  s->next = (pp_slab*)ctx->slabs;
+  if (s->next) s->next->prev = s;
+  ctx->slabs = s;
+  ctx->slabs_orphan = slabs_orphan;
   *out = s;
   return PP_OK;
 }
 
 extern "C" int32_t pp_slab_reset(pp_slab* s, const uint8_t* d_obs_slab) {
-  if (!s || !d_obs_slab) return PP_ERR_INVALID;
+  if (!s || !s->ctx || !d_obs_slab) return PP_ERR_INVALID;
   pp_ctx* ctx = s->ctx;
   PP_HIP(ctx, hipSetDevice(ctx->device));
   s->d.obs = d_obs_slab;
@@ -1327,16 +1366,20 @@ extern "C" int32_t pp_slab_reset(pp_slab* s, const uint8_t* d_obs_slab) {
 
 extern "C" void pp_slab_destroy(pp_slab* s) {
   if (!s) return;
-  (void)hipSetDevice(s->ctx->device);
-  (void)hipStreamSynchronize(s->ctx->stream);
-  if (s->buf) (void)hipFree(s->buf);
+  if (s->ctx) {
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->buf) (void)hipFree(s->buf);
+    if (s->prev) s->prev->next = s->next; else s->ctx->slabs = s->next;
+    if (s->next) s->next->prev = s->prev;
+  }
   delete s;
 }
 
 extern "C" int32_t pp_slab_relax(pp_slab* s, const double* d_halo_lo_new, const double* d_halo_hi_new,
                                  double limit, double* d_edge_lo, double* d_edge_hi, double* pending,
                                  uint64_t* iters) {
-  if (!s || limit != limit) return PP_ERR_INVALID;
+  if (!s || !s->ctx || limit != limit) return PP_ERR_INVALID;
   pp_ctx* ctx = s->ctx;
   PP_HIP(ctx, hipSetDevice(ctx->device));
   const uint64_t yw = s->d.yw;
@@ -1365,7 +1408,7 @@ extern "C" int32_t pp_slab_relax(pp_slab* s, const double* d_halo_lo_new, const 
 }
 
 extern "C" int32_t pp_slab_gather(pp_slab* s, uint64_t n, const uint64_t* d_x, const uint64_t* d_y, double* d_out) {
-  if (!s) return PP_ERR_INVALID;
+  if (!s || !s->ctx) return PP_ERR_INVALID;
   if (n == 0) return PP_OK;
   if (!d_x || !d_y || !d_out) return PP_ERR_INVALID;
   pp_ctx* ctx = s->ctx;
@@ -1382,7 +1425,7 @@ extern "C" int32_t pp_slab_gather(pp_slab* s, uint64_t n, const uint64_t* d_x, c
 }
 
 extern "C" int32_t pp_slab_read(pp_slab* s, double* d_cost_slab) {
-  if (!s || !d_cost_slab) return PP_ERR_INVALID;
+  if (!s || !s->ctx || !d_cost_slab) return PP_ERR_INVALID;
   pp_ctx* ctx = s->ctx;
   PP_HIP(ctx, hipSetDevice(ctx->device));
   DenseView d = s->d;

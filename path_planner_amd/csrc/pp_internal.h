@@ -85,6 +85,7 @@ struct pp_ctx {
   hipEvent_t wave_event = nullptr;  // that read-back
   void* ftab_buf = nullptr;  // the planner's per-query tables of known cells (pp_expand.h)
   size_t ftab_bytes = 0;
+  size_t ftab_budget = (size_t)16 << 30;  // device memory those tables may take (pp_ctx_set_table_budget)
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   // the planner's per-round device staging (grown on demand, never shrunk)
@@ -96,6 +97,10 @@ struct pp_ctx {
   // the planner's per-query host state, kept between calls (owned by pp_planner.hip)
   void* plan_state = nullptr;
   void (*plan_state_free)(void*) = nullptr;
+  // slab sessions created on this context and not yet destroyed (a list owned by pp_heuristic.hip);
+  // pp_ctx_destroy releases their device memory and leaves the handles inert
+  void* slabs = nullptr;
+  void (*slabs_orphan)(pp_ctx*) = nullptr;
 };
 
 struct pp_map {

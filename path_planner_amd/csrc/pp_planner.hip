@@ -976,7 +976,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   // the host never looks at them.  Short searches -- most of a typical batch -- never pay for it.
   constexpr uint32_t kFtabStartRound = 64;
   constexpr size_t kFtabMinLive = 64;
-  constexpr size_t kFtabBudget = (size_t)16 << 30;  // bytes of device memory for all tables
+  const size_t kFtabBudget = ctx->ftab_budget;  // bytes of device memory for all tables (pp_ctx_set_table_budget)
   // the cost bit patterns order like the costs only if no cost term can be negative
   bool ftab_off = !(plan.prm.backward_cost >= 0.0 && plan.prm.gear_cost >= 0.0 &&
                     plan.prm.steer_angle_cost >= 0.0 && plan.prm.steer_change_cost >= 0.0);
@@ -1004,13 +1004,28 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         ftab_off = true;
         return PP_OK;
       }
-      const size_t need = live * slots * 16;
+      // The tables only spare the host work: a smaller table rules out less, no table nothing, and
+      // the plans are the same.  So a device that has no room for them is not an error -- the
+      // tables shrink until they fit, or the batch goes on without them.
+      size_t need = live * slots * 16;
       if (need > ctx->ftab_bytes) {
         PP_HIP(ctx, hipStreamSynchronize(s));
         if (ctx->ftab_buf) PP_HIP(ctx, hipFree(ctx->ftab_buf));
         ctx->ftab_buf = nullptr;
         ctx->ftab_bytes = 0;
-        PP_HIP(ctx, hipMalloc(&ctx->ftab_buf, need));
+        for (;;) {
+          const hipError_t me = hipMalloc(&ctx->ftab_buf, need);
+          if (me == hipSuccess) break;
+          ctx->ftab_buf = nullptr;
+          (void)hipGetLastError();  // the failed allocation must not surface at the next launch check
+          if (me != hipErrorOutOfMemory) PP_HIP(ctx, me);
+          slots >>= 1;
+          need = live * slots * 16;
+          if (slots < 4096) {
+            ftab_off = true;
+            return PP_OK;
+          }
+        }
         ctx->ftab_bytes = need;
       }
       PP_HIP(ctx, hipMemsetAsync(ctx->ftab_buf, 0xFF, need, s));  // empty keys, values above every cost
@@ -1043,12 +1058,26 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
         *o++ = PpFtabUpd{sl.key, sl.state() == NodeTable::kClosed ? 0ull : f64_bits(sl.cost), q.ftab, 0};
       });
     });
+    // What the searches know so far goes over in pieces of whatever staging memory there is; with
+    // none at all the tables start empty and learn from the rounds to come.
+    size_t piece = total;
     void* tmp = nullptr;
-    PP_HIP(ctx, hipMalloc(&tmp, total * sizeof(PpFtabUpd)));
-    hipError_t e = hipMemcpyAsync(tmp, all.data(), total * sizeof(PpFtabUpd), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) {
-      pp_ftab_update_launch(ctx, (uint32_t)total, (const PpFtabUpd*)tmp, (unsigned long long*)ctx->ftab_buf, ftab_slots);
-      e = hipStreamSynchronize(s);  // `all` and tmp are about to go
+    for (;;) {
+      const hipError_t me = hipMalloc(&tmp, piece * sizeof(PpFtabUpd));
+      if (me == hipSuccess) break;
+      tmp = nullptr;
+      (void)hipGetLastError();
+      if (me != hipErrorOutOfMemory) PP_HIP(ctx, me);
+      if (piece <= 4096) return PP_OK;
+      piece = (piece + 1) / 2;
+    }
+    hipError_t e = hipSuccess;
+    for (size_t at = 0; at < total && e == hipSuccess; at += piece) {
+      const size_t m = std::min(piece, total - at);
+      e = hipMemcpyAsync(tmp, all.data() + at, m * sizeof(PpFtabUpd), hipMemcpyHostToDevice, s);
+      if (e != hipSuccess) break;
+      pp_ftab_update_launch(ctx, (uint32_t)m, (const PpFtabUpd*)tmp, (unsigned long long*)ctx->ftab_buf, ftab_slots);
+      e = hipStreamSynchronize(s);  // tmp is reused by the next piece, `all` and tmp go after the last
     }
     (void)hipFree(tmp);
     PP_HIP(ctx, e);

@@ -1,4 +1,5 @@
 """Parity of the obstacle-raster and wavefront kernels against the CPU oracle (bit-exact)."""
+import ctypes as C
 import json
 import math
 import os
@@ -273,3 +274,28 @@ def test_whole_grid_session_equals_the_dense_entry_point(ctx):
         sess.gather(torch.tensor([n + 1], device="cuda"), torch.tensor([0], device="cuda"))
     assert e.value.status == A.PP_ERR_BOUNDS
     sess.close()
+
+
+def test_slab_outlives_its_context():
+    """A context destroyed before its slab session takes the slab's device memory with it: the
+    handle then refuses every call and pp_slab_destroy still works (two sessions, one destroyed in
+    the right order first, so the context's list has been through an unlink)."""
+    import torch
+    from path_planner_amd.tiled import DeviceSlabSolver, make_slab
+    n = 200
+    own = api.Context(0)
+    obs, gx, gy = W.wavefront_obsmap(n, 0.2, seed=9)
+    slab_obs, _ = make_slab(obs, n, n, 0, n, "cuda")
+    torch.cuda.synchronize()
+    a = DeviceSlabSolver(own, n, n, 0, n, slab_obs, (gx, gy))
+    b = DeviceSlabSolver(own, n, n, 0, n, slab_obs, (gx, gy))
+    c = DeviceSlabSolver(own, n, n, 0, n, slab_obs, (gx, gy))
+    assert b.step(None, None, float("inf")) == float("inf")
+    b.close()
+    lib = own.lib
+    own.close()
+    for s in (a, c):
+        assert lib.pp_slab_relax(s.h, None, None, C.c_double(1.0), None, None, None, None) == A.PP_ERR_INVALID
+        assert lib.pp_slab_reset(s.h, slab_obs.data_ptr()) == A.PP_ERR_INVALID
+        lib.pp_slab_destroy(s.h)
+        s.h = None

@@ -369,6 +369,40 @@ def test_heuristic_grids_in_several_passes(ctx):
         O.set_max_expansions(0)
 
 
+def test_table_budget_does_not_change_a_batch(ctx):
+    """The device-side tables of known cells (searches still running after 64 rounds) only spare the
+    host work.  With the default budget, with one that forces small tables and with none at all
+    (pp_ctx_set_table_budget; the same path a device without room for them takes) every query comes
+    out the same."""
+    occ = W.plan_map(1024, 0.02)
+    m = api.ObstacleMap(ctx, raster=occ)
+    cs, cg = W.plan_queries(6000, 1024, 16, min_dist=20.0, max_dist=150.0)
+    fs = api.collision_flags(ctx, m, CONF, cs[:, 0], cs[:, 1], cs[:, 2])
+    fg = api.collision_flags(ctx, m, CONF, cg[:, 0], cg[:, 1], cg[:, 2])
+    inside = (cs[:, 0] > 8) & (cs[:, 0] < 1015) & (cs[:, 1] > 8) & (cs[:, 1] < 1015)
+    keep = np.nonzero(inside & (fs == 0) & (fg == 0))[0][:1400]
+    starts, goals = cs[keep], cg[keep]
+    ctx.set_max_expansions(300)
+    runs = []
+    try:
+        # 2^17 slots of 16 bytes per live query by default; 48 MiB leaves the hundred-odd queries still
+        # alive after 64 rounds 16384 slots each; 0 switches the tables off
+        for budget in (16 << 30, 48 << 20, 0):
+            ctx.set_table_budget(budget)
+            r = api.plan_batch(ctx, m, CONF, starts, goals, cap=2048, closed_cap=300)
+            runs.append({k: np.array(r[k], copy=True) for k in ("status", "len", "cost", "x", "y", "yaw", "dir", "closed")})
+            runs[-1]["exp"] = np.array([int(s.expansions) for s in r["stats"]])
+            runs[-1]["poses"] = np.array([int(s.poses_checked) for s in r["stats"]])
+    finally:
+        ctx.set_table_budget(16 << 30)
+        ctx.set_max_expansions(100000)
+    # enough searches outlive round 64 for the tables to be handed out
+    assert (runs[0]["exp"] > 80).sum() >= 64
+    for r in runs[1:]:
+        for k, v in runs[0].items():
+            assert np.array_equal(v, r[k], equal_nan=True), k
+
+
 def test_host_thread_count_does_not_change_a_batch(ctx):
     """pp_ctx_set_host_threads only says how many threads apply a round's results."""
     ox, oy = W.demo_obstacles()

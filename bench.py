@@ -15,6 +15,11 @@ scaling), `queries` (configs[4]: independent planner queries sharded over the ra
 `--heavy` = the search-heavy variant: denser map, longer queries), `expand` and `analytic` (the two
 per-expansion kernels on their own).
 
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself, as
+fresh child processes of a parent that never touches a GPU, relays rank 0's line and exits with the
+ranks' status.  When the box has fewer GPUs than ranks (a rehearsal) the ranks share the devices
+and their reductions travel over gloo; the line says so under config.rehearsal.
+
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (25 B/pose:
 3 x f64 in + 1 flag byte out) / the kernel's mean launch duration measured with events on the
 stream the kernel is launched on.  `cpu_baseline` = the CPU oracle (a port of the reference's
@@ -25,13 +30,16 @@ of the other BASELINE configs (rs 1 M pairs, wavefront 16384^2, 4096 queries on 
 light and its search-heavy form), each with its own ms_per_step, roofline and cpu_baseline; they
 run after the timed region of the headline workload and do not touch its numbers (--no-extra
 skips them).  With N > 1 the extra legs are the two workloads that shard for real -- the 4096
-queries dealt round-robin and the 16384^2 grid in x-slabs with its halo exchange -- under a
-watchdog (--extra-timeout): a leg that does not return never costs the headline line.
+queries dealt by goal group (strong: the fixed list over more ranks; and weak: 4096 queries per rank)
+and the 16384^2 grid in x-slabs with its halo exchange -- under a watchdog (--extra-timeout): a leg
+that does not return never costs the headline line, and the run then ends with exit status 3.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -66,6 +74,11 @@ def parse():
     ap.add_argument("--map", type=int, default=4096, help="queries workload map edge")
     ap.add_argument("--goals", type=int, default=64, help="distinct goals the queries share")
     ap.add_argument("--max-expansions", type=int, default=3000)
+    ap.add_argument("--deal", default="goal", choices=["goal", "roundrobin"],
+                    help="queries workload with several ranks: a rank gets whole goal groups (it then relaxes only "
+                         "its goals' heuristic grids) or every rank-th query of the list")
+    ap.add_argument("--weak", action="store_true",
+                    help="queries workload: --queries is the count per rank (weak scaling) instead of the total")
     ap.add_argument("--heavy", action="store_true",
                     help="queries workload: obstacle density 0.035 and starts 100-400 m from the goal "
                          "(the median query closes about a hundred nodes)")
@@ -334,23 +347,30 @@ def wl_queries(args, E):
     E.ctx.set_max_expansions(args.max_expansions)
     # candidates whose start or goal pose collides are dropped (device check), then the
     # first --queries survivors are dealt round-robin to the ranks
-    cs, cg = W.plan_queries((8 if args.heavy else 3) * args.queries, args.map, args.goals, min_dist=dmin, max_dist=dmax)
+    total = args.queries * (E.world if args.weak else 1)
+    cs, cg = W.plan_queries((8 if args.heavy else 3) * total, args.map, args.goals, min_dist=dmin, max_dist=dmax)
     inside = (cs[:, 0] > 8) & (cs[:, 0] < args.map - 9) & (cs[:, 1] > 8) & (cs[:, 1] < args.map - 9)
     fs = api.collision_flags(E.ctx, omap, E.conf, cs[:, 0], cs[:, 1], cs[:, 2])
     fg = api.collision_flags(E.ctx, omap, E.conf, cg[:, 0], cg[:, 1], cg[:, 2])
-    keep = np.nonzero(inside & (fs == 0) & (fg == 0))[0][: args.queries]
-    assert len(keep) == args.queries, "not enough collision-free candidates"
-    mine = E.S.query_shard(keep, E.rank, E.world)
+    keep = np.nonzero(inside & (fs == 0) & (fg == 0))[0][:total]
+    assert len(keep) == total, "not enough collision-free candidates"
+    if args.deal == "goal":
+        # the planner relaxes one heuristic grid per distinct goal cell (astar.rs:141-146) of its batch
+        cells = np.round(cg[keep][:, :2] / E.conf.xy_reso).astype(np.int64)
+        mine = keep[E.S.query_shard_by_goal(cells, E.rank, E.world)]
+    else:
+        mine = E.S.query_shard(keep, E.rank, E.world)
     starts, goals = cs[mine], cg[mine]
     wl = SimpleNamespace(
         units=len(mine), bytes_per_unit=0.0, metric="planning_queries_per_sec", unit="queries/s",
-        scaling="strong", dtype="f64", kernel="k_round / k_rs_words+k_rs_shot+k_expand", bound="latency",
-        counters_key=None,
-        config={"workload": f"{args.queries} hybrid A* queries on a {args.map}x{args.map} map (border + "
+        scaling="weak" if args.weak else "strong", dtype="f64", kernel="k_round / k_rs_words+k_rs_shot+k_expand",
+        bound="latency", counters_key=None,
+        config={"workload": f"{total} hybrid A* queries on a {args.map}x{args.map} map (border + "
                             f"clustered wall segments, density {occ.mean():.4f}), {args.goals} shared goals, "
                             f"start {dmin:.0f}-{dmax:.0f} m from goal, expansion cap {args.max_expansions}",
-                "queries": args.queries, "variant": "search-heavy" if args.heavy else "light",
-                "parallelism": f"query-sharded x{E.world}"})
+                "queries": total, "variant": "search-heavy" if args.heavy else "light",
+                "parallelism": f"query-sharded x{E.world}",
+                "deal": ("whole goal groups per rank" if args.deal == "goal" else "round-robin") if E.world > 1 else None})
     last = {}
 
     def step():
@@ -373,12 +393,22 @@ def wl_queries(args, E):
             "rs_paths": int(sum(stt[i].rs_paths for i in range(nq))),
             "t_heuristic_ms": float(stt[0].t_heuristic_ms), "t_search_ms": float(stt[0].t_search_ms),
             "note": "counters of rank 0's shard, last step"}
+        # what sets the time of a lock-step batch, per rank: the grids it relaxes, its rounds (and how many of
+        # them ran with the chip nearly empty) and its longest query
+        mine_c = dict(api.plan_batch_counters(E.ctx), t_heuristic_ms=float(stt[0].t_heuristic_ms),
+                      t_search_ms=float(stt[0].t_search_ms), cap_reached=int((r["status"] == A.PP_ERR_LIMIT).sum()))
+        if E.world > 1:
+            allc = [None] * E.world
+            E.dist.all_gather_object(allc, mine_c)
+            out["search"]["per_rank"] = allc
+        else:
+            out["search"]["per_rank"] = [mine_c]
     wl.finish = finish
 
     def cpu(O):
         from concurrent.futures import ThreadPoolExecutor
-        nt = args.cpu_sample or 8      # timed one after the other on one core
-        nc = 64 if args.heavy else 16  # checked against the device result (the rest on a thread pool)
+        nt = args.cpu_sample or 32     # timed one after the other on one core
+        nc = 64                        # checked against the device result (the rest on a thread pool)
         om = O.OracleMap(*W.raster_to_points(occ))
         O.set_max_expansions(args.max_expansions)
         r = last["r"]
@@ -433,8 +463,33 @@ def roofline(wl, dev_ms):
                     "neither HBM nor the ALUs bound it (see the search counters)"}
 
 
+def self_launch(args):
+    """`--gpus N` with no launcher around it: start the N ranks as fresh processes (torch's own
+    launcher, one rank per GPU), relay what rank 0 prints and leave with the ranks' exit status.
+    This process never initialises a GPU."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = 0
+    for ln in child.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+        lines += ln.startswith("{")
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: the ranks printed {lines} result lines, expected 1", file=sys.stderr)
+        rc = 4
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
 
@@ -446,10 +501,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # PP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks:
-    # ranks share the devices round-robin and the reductions travel through host memory.
-    backend = os.environ.get("PP_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    # A box with fewer GPUs than ranks can only rehearse the multi-rank path: the ranks share the
+    # devices round-robin and the reductions travel through host memory (gloo).  PP_BENCH_BACKEND
+    # forces either backend.
+    ndev = max(torch.cuda.device_count(), 1)  # counting devices does not initialise one
+    local_world_env = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    backend = os.environ.get("PP_BENCH_BACKEND") or ("nccl" if ndev >= local_world_env else "gloo")
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -476,7 +534,10 @@ def main():
         conf.car.center2front, conf.car.center2back, conf.car.width, conf.extend_bound = 3.0, 1.0, 1.8, 0.2
     if args.band > 0:
         assert ctx.lib.pp_ctx_set_relax_band(ctx.h, args.band) == 0
-    E = SimpleNamespace(torch=torch, api=api, W=W, A=A, S=S, ctx=ctx, conf=conf, dev=dev, rank=rank, world=world)
+    E = SimpleNamespace(torch=torch, api=api, W=W, A=A, S=S, ctx=ctx, conf=conf, dev=dev, rank=rank, world=world,
+                        dist=dist)
+    rehearsal = (f"{world} ranks on {ndev} GPU(s), reductions over {backend}: a rehearsal of the multi-rank path, "
+                 "not a scaling measurement") if world > 1 and (backend != "nccl" or ndev < local_world_env) else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -506,6 +567,8 @@ def main():
                "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
                "scaling": wl.scaling, "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
                "config": wl.config, "roofline": roofline(wl, dev_ms)}
+        if rehearsal:
+            out["config"]["rehearsal"] = rehearsal
         if getattr(wl, "finish", None):
             wl.finish(out)
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -561,15 +624,25 @@ def main():
         torch.cuda.empty_cache()
         out["extra"] = {}
 
+        in_flight = ["(none)"]
+
         def give_up():
-            out["extra"]["watchdog"] = f"extra legs stopped after {args.extra_timeout} s"
+            # a process that has used the GPU and gives up on a collective must not report success:
+            # the line (headline first) still goes out, then every rank leaves with status 3.  Rank 0
+            # goes first so that the launcher, which ends the others when one rank fails, cannot cut
+            # its line off.
+            out["extra"]["watchdog"] = f"extra legs stopped after {args.extra_timeout} s, in leg '{in_flight[0]}'"
             emit()
-            os._exit(0)
+            if rank != 0:
+                time.sleep(5.0)
+            os._exit(3)
         dog = threading.Timer(args.extra_timeout, give_up)
         dog.daemon = True
         dog.start()
         for name, over, steps, warmup in [("queries", {"workload": "queries"}, 2, 1),
+                                          ("queries_weak", {"workload": "queries", "weak": True}, 2, 1),
                                           ("wavefront", {"workload": "wavefront"}, 2, 1)]:
+            in_flight[0] = name
             # sizes as given on the command line (the BASELINE sizes unless a rehearsal shrinks them)
             a = argparse.Namespace(**{**vars(args), **over, "no_cpu_baseline": True})
             try:

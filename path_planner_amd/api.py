@@ -236,6 +236,14 @@ def wavefront_stats(ctx):
     return dict(zip(("rounds", "tile_visits", "sweep_pairs", "tiles"), (int(v) for v in out)))
 
 
+def plan_batch_counters(ctx):
+    """Work counters of the context's last plan_batch (pp_plan_batch_counters)."""
+    out = np.zeros(8, np.uint64)
+    _chk(ctx.lib.pp_plan_batch_counters(ctx.h, _p(out, C.c_uint64)), "pp_plan_batch_counters")
+    return dict(zip(("rounds", "rounds_under_64_live", "nodes_sent", "goal_grids", "longest_query_expansions",
+                     "expansions", "queries", "lanes"), (int(v) for v in out)))
+
+
 # ------------------------------------------------------------------ Reeds-Shepp
 def _cols(q):
     q = _f64(q).reshape(-1, 3)

@@ -97,6 +97,7 @@ struct pp_ctx {
   // the planner's per-query host state, kept between calls (owned by pp_planner.hip)
   void* plan_state = nullptr;
   void (*plan_state_free)(void*) = nullptr;
+  uint64_t plan_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // last pp_plan_batch (pp_plan_batch_counters)
   // slab sessions created on this context and not yet destroyed (a list owned by pp_heuristic.hip);
   // pp_ctx_destroy releases their device memory and leaves the handles inert
   void* slabs = nullptr;

@@ -899,6 +899,7 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   const bool prof = getenv("PP_PLAN_PROFILE") != nullptr;
   double p_adv[2] = {0, 0}, p_stage[2] = {0, 0}, p_dev[2] = {0, 0}, p_apply[2] = {0, 0};
   uint64_t p_rounds[2] = {0, 0}, p_items[2] = {0, 0}, p_live[2] = {0, 0};
+  uint64_t c_rounds = 0, c_small = 0, c_items = 0;  // always counted: pp_plan_batch_counters
 
   // A lane is a set of queries that go through their rounds together.  A large batch runs as two
   // lanes that take turns: while the device works on one lane's nodes, the host applies the other
@@ -1181,6 +1182,9 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
       }, 1, 2);
     }
     const double p2 = prof ? now_ms() : 0.0;
+    ++c_rounds;
+    if (nl < 64) ++c_small;
+    c_items += ni;
     if (prof) {
       p_stage[ln.pc] += p2 - p1;
       ++p_rounds[ln.pc];
@@ -1500,6 +1504,22 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
             x1 - x0, x2 - x1, t_extract - x2, nroll_all);
   if (getenv("PP_PLAN_PROFILE"))
     fprintf(stderr, "[plan] entry->begin %.1f heur %.1f search(incl. staging alloc) %.1f extract %.1f ms\n", t_begin - t_entry, t_heur - t_begin, t_search - t_heur, t_extract - t_search);
+  {
+    uint64_t longest = 0, closed = 0;
+    for (uint64_t i = 0; i < nq; ++i) {
+      longest = std::max<uint64_t>(longest, Q[i].st.expansions);
+      closed += Q[i].st.expansions;
+    }
+    uint64_t* c = ctx->plan_counters;
+    c[0] = c_rounds;
+    c[1] = c_small;
+    c[2] = c_items;
+    c[3] = ngoals;
+    c[4] = longest;
+    c[5] = closed;
+    c[6] = nq;
+    c[7] = (uint64_t)nlanes;
+  }
   for (uint64_t i = 0; i < nq; ++i) {
     Query& q = Q[i];
     q.st.t_heuristic_ms = t_heur - t_begin;
@@ -1519,6 +1539,12 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     if (Q[i].nodes.capacity() > (1u << 16)) Q[i] = Query();
   if (getenv("PP_PLAN_PROFILE")) fprintf(stderr, "[plan] teardown %.1f ms\n", now_ms() - t_extract);
   return ret;
+}
+
+extern "C" int32_t pp_plan_batch_counters(pp_ctx* ctx, uint64_t out[8]) {
+  if (!ctx || !out) return PP_ERR_INVALID;
+  std::memcpy(out, ctx->plan_counters, sizeof(ctx->plan_counters));
+  return PP_OK;
 }
 
 extern "C" int32_t pp_plan(pp_ctx* ctx, const pp_map* map, const pp_config* conf,

@@ -24,9 +24,55 @@ def pair_shard(n_per_rank, rank, extent=100.0):
 
 
 def query_shard(ids, rank, world):
-    """This rank's share of a fixed list of queries: dealt round-robin, so long and short
-    queries (the list is ordered by goal) spread evenly."""
+    """This rank's share of a fixed list of queries, dealt round-robin: long and short queries
+    spread evenly, and so do the goals -- every rank then relaxes every goal's heuristic grid
+    (see query_shard_by_goal for the deal that keeps goal groups together)."""
     return ids[rank::world]
+
+
+def goal_order(goal_keys):
+    """Positions of a query list ordered by goal (stable: queries of one goal keep their order).
+    goal_keys: one hashable-by-value row per query (e.g. the goal's heuristic-grid cell)."""
+    keys = np.asarray(goal_keys)
+    keys = keys.reshape(len(keys), -1)
+    _, inv = np.unique(keys, axis=0, return_inverse=True)
+    return np.argsort(np.asarray(inv).reshape(-1), kind="stable")
+
+
+def query_shard_by_goal(goal_keys, rank, world):
+    """Positions (into the undealt list) of this rank's share when the list is dealt by goal: the
+    queries are ordered by goal and cut into `world` runs of equal length (+-1), so a rank holds
+    whole goal groups except for at most one group shared with each neighbour.  The planner
+    relaxes one heuristic grid per distinct goal cell of its batch: dealt this way a rank relaxes
+    about n_goals / world + 1 grids instead of all of them, at equal query counts.  (Queries of
+    different goals can differ in length, so the shares are equal in queries, not in work.)"""
+    order = goal_order(goal_keys)
+    n = len(order)
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    return np.sort(order[lo:hi])
+
+
+def gather_by_position(part, positions, rank, world, total, group=None):
+    """Rank 0 gets the per-query rows back in the order of the undealt list, whatever the deal:
+    every rank sends its rows with the positions they belong at.  Other ranks get None."""
+    part = np.ascontiguousarray(part)
+    positions = np.asarray(positions, dtype=np.int64)
+    if world == 1:
+        out = np.empty((total,) + part.shape[1:], dtype=part.dtype)
+        out[positions] = part
+        return out
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object((positions, part), parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = np.empty((total,) + part.shape[1:], dtype=part.dtype)
+    seen = np.zeros(total, dtype=bool)
+    for pos, p in parts:
+        assert not seen[pos].any(), "a query was dealt twice"
+        seen[pos] = True
+        out[pos] = p
+    assert seen.all(), "a query was not dealt"
+    return out
 
 
 def gather_slices(part, rank, world, group=None):

@@ -131,6 +131,18 @@ def main():
         exp = eng.plans(cs[keep], cg[keep])
         report.append(("queries", same_bits(got, exp), int((exp[:, 0] == 0).sum())))
 
+    # the same list dealt by goal group (a rank then needs the heuristic grids of its goals only)
+    cells = np.round(cg[keep][:, :2] / CONF.xy_reso).astype(np.int64)
+    pos = S.query_shard_by_goal(cells, rank, world)
+    mine_g = keep[pos]
+    got = S.gather_by_position(eng.plans(cs[mine_g], cg[mine_g]), pos, rank, world, len(keep))
+    my_goals = len({tuple(c) for c in cells[pos]})
+    all_goals = len({tuple(c) for c in cells})
+    fewer = S.sum_over_ranks(my_goals, "cpu")
+    if rank == 0:
+        # at most one goal group is shared with each neighbour
+        report.append(("by_goal", same_bits(got, exp) and fewer <= all_goals + world - 1, int(fewer)))
+
     # the totals of a sharded run: one all-reduce
     total = S.sum_over_ranks(len(mine), "cpu")
     if rank == 0:

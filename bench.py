@@ -185,11 +185,16 @@ def wl_rs(args, E):
         t0 = time.perf_counter()
         st, enp, ebest, ewords, eflags = O.rs_batch(q0[:ns], q1[:ns], maxc, threads=1)
         dt = time.perf_counter() - t0
-        clean = (rflags[:ns].cpu().numpy() & 2) == 0
-        mism = int(((npaths[:ns].cpu().numpy() != enp) & clean).sum() + ((best[:ns].cpu().numpy() != ebest) & clean).sum())
+        fl = rflags[:ns].cpu().numpy()
+        accept, tie = (fl & 2) != 0, (fl & 10) == 8
+        clean = (fl & 10) == 0
+        # word count: equal unless an accept / duplicate test fell inside the guard band; selected index:
+        # equal unless, besides, the minimum is tied
+        mism = int(((npaths[:ns].cpu().numpy() != enp) & ~accept).sum() + ((best[:ns].cpu().numpy() != ebest) & clean).sum())
         return {"value": ns / dt, "unit": wl.unit, "cores": 1, "kind": "port",
                 "sample": f"first {ns} pairs, CPU oracle generate_path + argmin",
-                "mismatches_vs_gpu": mism, "guard_band_pairs": int((~clean).sum())}
+                "mismatches_vs_gpu": mism, "guard_band_pairs": int((~clean).sum()),
+                "guard_band_share": {"accept_or_duplicate_test": float(accept.mean()), "tie_at_minimum_only": float(tie.mean())}}
     wl.cpu = cpu
     return wl
 

@@ -1248,6 +1248,27 @@ int32_t orc_rs_batch(uint64_t n, const double* sx, const double* sy, const doubl
   return PP_OK;
 }
 
+int32_t orc_rs_words_batch(uint64_t n, const double* sx, const double* sy, const double* syaw,
+                           const double* gx, const double* gy, const double* gyaw, double maxc,
+                           int32_t* n_paths, pp_rs_word* words, int32_t threads) {
+  (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+#endif
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    std::vector<FullPath> paths;
+    pp_rs_word* out = words + (size_t)i * PP_RS_MAX_PATHS;
+    std::memset(out, 0, sizeof(pp_rs_word) * PP_RS_MAX_PATHS);
+    if (!calc_all_paths(sx[i], sy[i], syaw[i], gx[i], gy[i], gyaw[i], maxc, 0.0, paths, false)) {
+      n_paths[i] = -1;  // the :157 assert
+      continue;
+    }
+    n_paths[i] = (int32_t)paths.size();
+    for (size_t k = 0; k < paths.size(); ++k) to_abi(paths[k].w, &out[k]);
+  }
+  return PP_OK;
+}
+
 double orc_rs_path_cost(const pp_rs_word* w, const pp_config* conf) {
   return rs_path_cost(w->lengths, w->ctypes, w->nseg, *conf);
 }

@@ -92,6 +92,11 @@ int32_t orc_rs_batch(uint64_t n, const double *sx, const double *sy, const doubl
                      const double *gx, const double *gy, const double *gyaw, double maxc,
                      int32_t *n_paths, int32_t *best_idx, pp_rs_word *best, uint8_t *flags,
                      int32_t threads);
+/* generate_path (src/reeds_shepp.rs:707-725) for n pairs: every word of pair i in generation order at
+ * words[i * PP_RS_MAX_PATHS ..], n_paths[i] of them (-1: the :157 assert fires) */
+int32_t orc_rs_words_batch(uint64_t n, const double *sx, const double *sy, const double *syaw,
+                           const double *gx, const double *gy, const double *gyaw, double maxc,
+                           int32_t *n_paths, pp_rs_word *words, int32_t threads);
 /* src/hybrid_astar.rs:450-489 */
 double orc_rs_path_cost(const pp_rs_word *word, const pp_config *conf);
 /* src/hybrid_astar.rs:380-415 for n (start, goal) pairs */

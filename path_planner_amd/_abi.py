@@ -169,6 +169,8 @@ def load_library(path=None):
         "pp_slab_destroy": (None, [vp]),
         "pp_rs_batch": (C.c_int32, [vp, C.c_uint64, d, d, d, d, d, d, C.c_double, i32, i32,
                                     C.POINTER(RsWord), u8]),
+        "pp_rs_words_batch": (C.c_int32, [vp, C.c_uint64, d, d, d, d, d, d, C.c_double, i32,
+                                          C.POINTER(RsWord), u8]),
         "pp_rs_batch_dev": (C.c_int32, [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_double, vp, vp,
                                         vp, vp]),
         "pp_rs_all_paths": (C.c_int32, [vp] + [C.c_double] * 8 + [i32, C.POINTER(RsWord), u64, d, d,

@@ -263,6 +263,19 @@ def rs_batch(ctx, q0, q1, maxc):
     return npaths, best, words, flags
 
 
+def rs_words_batch(ctx, q0, q1, maxc):
+    """generate_path (reeds_shepp.rs:707-725) for n pairs, every word kept: (n_paths[n], RsWord array
+    of n * PP_RS_MAX_PATHS with pair i's words from i * PP_RS_MAX_PATHS on, flags[n])."""
+    s, g = _cols(q0), _cols(q1)
+    n = len(s[0])
+    npaths = np.zeros(n, np.int32)
+    words = (A.RsWord * (n * A.PP_RS_MAX_PATHS))()
+    flags = np.zeros(n, np.uint8)
+    _chk(ctx.lib.pp_rs_words_batch(ctx.h, n, *[_p(c) for c in s + g], maxc, _p(npaths, C.c_int32), words,
+                                   _p(flags, C.c_uint8)), "pp_rs_words_batch")
+    return npaths, words, flags
+
+
 def calc_all_paths(ctx, sx, sy, syaw, gx, gy, gyaw, maxc, step_size, traj_cap=400000):
     """reeds_shepp.rs:87-128.  Returns a list of dicts (ctypes, lengths, total, x, y, yaw, dir)."""
     n = C.c_int32(0)

@@ -98,7 +98,7 @@ k_rs_batch(uint64_t n, const double* __restrict__ sx, const double* __restrict__
       best_idx[i] = __popcll(S.accepted & ((1ull << sink.best_gen) - 1ull));
       write_word(&best[i], sink.best_word, sink.best_n, sink.best_len, sink.best_total, maxc);
     }
-    flags[i] = (S.A.amb || sink.near_tie) ? 2 : 0;
+    flags[i] = (S.A.amb ? 2 : 0) | (sink.near_tie ? 8 : 0);
   }
 }
 
@@ -965,6 +965,59 @@ extern "C" int32_t pp_rs_batch(pp_ctx* ctx, uint64_t n, const double* sx, const 
   PP_HIP(ctx, hipMemcpyAsync(best, d_w, n * sizeof(pp_rs_word), hipMemcpyDeviceToHost, s));
   PP_HIP(ctx, hipMemcpyAsync(flags, d_f, n, hipMemcpyDeviceToHost, s));
   PP_HIP(ctx, hipStreamSynchronize(s));
+  return PP_OK;
+}
+
+// generate_path for n pairs with every word kept (host pointers): pair i's words in generation
+// order at words[i * PP_RS_MAX_PATHS ..], n_paths[i] of them.
+extern "C" int32_t pp_rs_words_batch(pp_ctx* ctx, uint64_t n, const double* sx, const double* sy,
+                                     const double* syaw, const double* gx, const double* gy,
+                                     const double* gyaw, double maxc, int32_t* n_paths, pp_rs_word* words,
+                                     uint8_t* flags) {
+  if (!ctx) return PP_ERR_INVALID;
+  if (n == 0) return PP_OK;
+  if (n > 0x7fffffffu) return PP_ERR_UNSUPPORTED;
+  if (!sx || !sy || !syaw || !gx || !gy || !gyaw || !n_paths || !words || !flags) return PP_ERR_INVALID;
+  PP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t a_q = al256(6 * n * 8), a_c = al256(n * PP_RS_MAX_PATHS * sizeof(PpRsCand));
+  int32_t st = pp_scratch_reserve(ctx, a_q + a_c + al256(n * sizeof(PpRsPair)));
+  if (st != PP_OK) return st;
+  char* b = (char*)ctx->scratch;
+  double* d_q = (double*)b;
+  PpRsCand* d_c = (PpRsCand*)(b + a_q);
+  PpRsPair* d_p = (PpRsPair*)(b + a_q + a_c);
+  const double* hq[6] = {sx, sy, syaw, gx, gy, gyaw};
+  hipStream_t s = ctx->stream;
+  for (int k = 0; k < 6; ++k) PP_HIP(ctx, hipMemcpyAsync(d_q + k * n, hq[k], n * 8, hipMemcpyHostToDevice, s));
+  pp_rs_words_launch(ctx, n, d_q, maxc, d_c, d_p);
+  PP_HIP(ctx, hipGetLastError());
+  std::vector<PpRsCand> hc(n * PP_RS_MAX_PATHS);
+  std::vector<PpRsPair> hp(n);
+  PP_HIP(ctx, hipMemcpyAsync(hc.data(), d_c, hc.size() * sizeof(PpRsCand), hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipMemcpyAsync(hp.data(), d_p, n * sizeof(PpRsPair), hipMemcpyDeviceToHost, s));
+  PP_HIP(ctx, hipStreamSynchronize(s));
+  for (uint64_t i = 0; i < n; ++i) {
+    pp_rs_word* out = words + i * PP_RS_MAX_PATHS;
+    std::memset(out, 0, sizeof(pp_rs_word) * PP_RS_MAX_PATHS);
+    const bool degenerate = (hp[i].flags & 4u) != 0;
+    flags[i] = (uint8_t)((degenerate ? 1u : 0u) | (hp[i].flags & 2u));
+    n_paths[i] = degenerate ? 0 : hp[i].n_paths;
+    if (degenerate) continue;
+    uint64_t m = hp[i].accepted;
+    int k = 0;
+    while (m) {
+      const int g = __builtin_ctzll(m);
+      m &= m - 1;
+      const PpRsCand& c = hc[i * PP_RS_MAX_PATHS + g];
+      pp_rs_word& w = out[k++];
+      for (int j = 0; j < c.nseg; ++j) {
+        w.lengths[j] = c.len[j] / maxc;  // :124
+        w.ctypes[j] = pp_word_letter(c.word, j);
+      }
+      w.nseg = (uint8_t)c.nseg;
+      w.total_length = c.total / maxc;   // :125
+    }
+  }
   return PP_OK;
 }
 

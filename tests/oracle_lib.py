@@ -55,6 +55,7 @@ def lib():
         "orc_rs_all_paths": (C.c_int32, [C.c_double] * 8 + [i32, W, u64, d, d, d, i64, C.c_uint64]),
         "orc_rs_batch": (C.c_int32, [C.c_uint64, d, d, d, d, d, d, C.c_double, i32, i32, W, u8,
                                      C.c_int32]),
+        "orc_rs_words_batch": (C.c_int32, [C.c_uint64, d, d, d, d, d, d, C.c_double, i32, W, C.c_int32]),
         "orc_rs_path_cost": (C.c_double, [W, cfg]),
         "orc_analytic_batch": (C.c_int32, [vp, cfg, C.c_uint64, d, d, d, d, d, d, u8, i32, i32, W, d]),
         "orc_plan": (C.c_int32, [vp, cfg, d, d, C.POINTER(A.Path), C.POINTER(A.PlanStats)]),
@@ -266,6 +267,19 @@ def rs_batch(s, g, maxc, threads=1):
     st = lib().orc_rs_batch(n, *[_p(c) for c in cols], maxc, _p(npaths, C.c_int32),
                             _p(best, C.c_int32), words, _p(flags, C.c_uint8), threads)
     return st, npaths, best, words, flags
+
+
+def rs_words_batch(s, g, maxc, threads=8):
+    """generate_path's words for n pairs: (n_paths[n] (-1 = degenerate), RsWord array of n * 46)."""
+    s, g = _f64(s).reshape(-1, 3), _f64(g).reshape(-1, 3)
+    n = len(s)
+    cols = [np.ascontiguousarray(s[:, k]) for k in range(3)] + \
+           [np.ascontiguousarray(g[:, k]) for k in range(3)]
+    npaths = np.zeros(n, np.int32)
+    words = (A.RsWord * (n * A.PP_RS_MAX_PATHS))()
+    st = lib().orc_rs_words_batch(n, *[_p(c) for c in cols], maxc, _p(npaths, C.c_int32), words, threads)
+    assert st == 0, st
+    return npaths, words
 
 
 def rs_path_cost(word, conf):

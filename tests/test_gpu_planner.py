@@ -93,6 +93,8 @@ FLAGGED_FIXTURE = 0
 FLAGGED_DEMO_RANDOM = 0
 FLAGGED_BATCH40 = 0
 FLAGGED_BATCH96 = 0
+FLAGGED_TWO_LANES = 0    # the 72 sampled queries of the 1500-query batch
+FLAGGED_SEVERAL_PASSES = 0
 
 
 def test_random_queries_on_demo_map(ctx):
@@ -256,7 +258,8 @@ def test_large_batch_in_two_lanes_equals_small_batches_and_oracle(ctx):
         for i in list(range(0, 1500, 47)) + list(np.argsort(big_exp)[-40:]):
             e = om.plan(CONF, starts[i], goals[i])
             differ += not same_batch_query(big, int(i), e, 400)
-        assert differ <= 2, differ
+        print("differing after a guard-band decision:", differ)
+        assert differ <= FLAGGED_TWO_LANES, differ
     finally:
         ctx.set_max_expansions(100000)
         O.set_max_expansions(0)
@@ -362,7 +365,8 @@ def test_heuristic_grids_in_several_passes(ctx):
         for i in range(0, len(starts), 8):
             e = om.plan(CONF, starts[i], goals[i])
             differ += not same_batch_query(last, int(i), e, 800)
-        assert differ <= 1, differ
+        print("differing after a guard-band decision:", differ)
+        assert differ <= FLAGGED_SEVERAL_PASSES, differ
     finally:
         ctx.set_heuristic_workspace(8 << 30)
         ctx.set_max_expansions(100000)

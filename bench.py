@@ -92,6 +92,8 @@ def parse():
                     help="wavefront obstacle raster: Bernoulli(0.2) or long walls with one gap each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs of the default run")
+    ap.add_argument("--no-floors", action="store_true",
+                    help="collision workload: do not run tools/k2_floors (the access-pattern floors) after the timed region")
     ap.add_argument("--extra-timeout", type=float, default=240.0,
                     help="seconds the extra legs of a multi-rank run may take before the line is printed without them")
     ap.add_argument("--cpu-sample", type=int, default=0)
@@ -127,6 +129,36 @@ def wl_collision(args, E):
                             f"occupancy grid (border + Bernoulli 0.05), {args.car} car",
                 "poses_per_gpu": n, "grid": args.grid, "parallelism": f"pose-sharded x{E.world}"})
     wl.step = lambda: api.collision_flags_dev(E.ctx, omap, E.conf, dx, dy, dyaw, flags)
+
+    def finish(out):
+        # Where 8 TB/s is out of reach for this access pattern, by measurement in the same run: the
+        # floor of streaming the poses alone, and of streaming them with one random L2 line per pose
+        # (tools/k2_floors.hip, no arithmetic).  Uniformly random poses share no obstacle data, so
+        # every per-pose lookup kernel sits on the second floor at best.
+        exe = os.path.join(ROOT, "tools", "k2_floors")
+        r = out["roofline"]
+        r["hbm_peak_note"] = ("0.60 of the 8 TB/s figure is not reachable in this formulation: the input stream alone "
+                              "runs at stream_floor_ms, and one random obstacle line per pose at gather_floor_ms")
+        try:
+            if E.rank != 0 or not os.path.exists(exe) or args.no_floors:
+                raise FileNotFoundError(exe)
+            E.torch.cuda.synchronize()
+            fl = json.loads(subprocess.run([exe, str(n), "20"], capture_output=True, text=True, timeout=120,
+                                           check=True).stdout.strip().splitlines()[-1])
+            src = "tools/k2_floors run after the timed region"
+        except Exception:
+            fl = (measured_counters("collision_floors", n) or {}).get("floors")
+            src = "profiles/counters.json"
+        if fl:
+            k = r["kernel_ms"]
+            r.update({"stream_floor_ms": fl["stream_only_ms"], "gather_floor_ms": fl["stream_plus_one_line_ms"],
+                      "own_pattern_floor_ms": fl["stream_plus_four_gathers_ms"],
+                      "frac_of_stream_floor": fl["stream_only_ms"] / k, "frac_of_gather_floor": fl["stream_plus_one_line_ms"] / k,
+                      "frac_of_own_pattern_floor": fl["stream_plus_four_gathers_ms"] / k,
+                      "ceiling_frac_any_kernel": wl.units * BYTES_PER_POSE / (fl["stream_only_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "ceiling_frac_per_pose_lookup": wl.units * BYTES_PER_POSE / (fl["stream_plus_one_line_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "floors_source": src})
+    wl.finish = finish
 
     def cpu(O):
         om = O.OracleMap(*W.raster_to_points(occ))

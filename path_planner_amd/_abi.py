@@ -186,6 +186,8 @@ def load_library(path=None):
         "pp_plan": (C.c_int32, [vp, vp, cfg, d, d, C.POINTER(Path), C.POINTER(PlanStats)]),
         "pp_plan_batch": (C.c_int32, [vp, vp, cfg, C.c_uint64, d, d, C.POINTER(Path),
                                       C.POINTER(PlanStats), i32]),
+        "pp_plan_batch_multi": (C.c_int32, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_uint32, cfg,
+                                            C.c_uint64, d, d, C.POINTER(Path), C.POINTER(PlanStats), i32]),
         "pp_astar_plan": (C.c_int32, [vp, vp] + [C.c_double] * 6 + [d, d, C.c_uint64, u64, u64,
                                                                     C.c_uint64, u64]),
         "pp_astar_plan_batch": (C.c_int32, [vp, vp, C.c_uint64, d, d, C.c_double, C.c_double, d, d,

@@ -372,7 +372,9 @@ def plan_batch(ctx, omap, conf, starts, goals, cap=4096, closed_cap=0, out=None)
     """n independent hybrid_astar_planning calls advanced together (pp_plan_batch).  Returns
     status[n], a list-like of paths (x, y, yaw, dir arrays of shape (n, cap) with len[n], cost[n])
     and the per-query statistics.  `out` = the result of an earlier call of the same shape: its
-    path arrays are written again instead of allocating (and page-faulting in) new ones."""
+    path arrays are written again instead of allocating (and page-faulting in) new ones.
+    With lists of contexts and maps (maps[k] created on ctxs[k]) the queries are dealt over the
+    contexts by goal, one host thread each (pp_plan_batch_multi)."""
     starts = np.ascontiguousarray(_f64(starts).reshape(-1, 3))
     goals = np.ascontiguousarray(_f64(goals).reshape(-1, 3))
     n = len(starts)
@@ -398,9 +400,18 @@ def plan_batch(ctx, omap, conf, starts, goals, cap=4096, closed_cap=0, out=None)
             stats[i].closed_cap = closed_cap
             stats[i].closed_order = C.cast(cs + i * closed_cap * 8, up)
     status = np.zeros(n, np.int32)
-    st = ctx.lib.pp_plan_batch(ctx.h, omap.h, C.byref(conf), n, _p(starts), _p(goals), paths, stats,
-                               _p(status, C.c_int32))
-    _chk(st, "pp_plan_batch")
+    if isinstance(ctx, (list, tuple)):
+        k = len(ctx)
+        assert k == len(omap) and k >= 1
+        hc = (C.c_void_p * k)(*[c.h for c in ctx])
+        hm = (C.c_void_p * k)(*[m.h for m in omap])
+        st = ctx[0].lib.pp_plan_batch_multi(hc, hm, k, C.byref(conf), n, _p(starts), _p(goals), paths, stats,
+                                            _p(status, C.c_int32))
+        _chk(st, "pp_plan_batch_multi")
+    else:
+        st = ctx.lib.pp_plan_batch(ctx.h, omap.h, C.byref(conf), n, _p(starts), _p(goals), paths, stats,
+                                   _p(status, C.c_int32))
+        _chk(st, "pp_plan_batch")
     lens = pt["len"].astype(np.int64)
     cost = pt["cost"].copy()
     return {"status": status, "x": X, "y": Y, "yaw": YAW, "dir": D, "len": lens, "cost": cost,

@@ -1556,3 +1556,87 @@ extern "C" int32_t pp_plan(pp_ctx* ctx, const pp_map* map, const pp_config* conf
   if (st != PP_OK) return st;
   return status;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The batch over several devices of one process: context k (with the obstacle map created on it)
+// takes a share of the queries, a host thread per context runs pp_plan_batch on it, and every
+// result lands at its query's place in the caller's arrays.  The queries are dealt by goal: ordered
+// by the heuristic-grid cell of their goal (astar.rs:141-146) and cut into n_ctx runs of equal
+// length, so a context relaxes the grids of its own goals only -- about (distinct goals) / n_ctx + 1
+// of them -- and no data travels between devices.  A query's result does not depend on the batch
+// it is planned in, so the outcome equals pp_plan_batch over the whole list on one context.
+extern "C" int32_t pp_plan_batch_multi(pp_ctx* const* ctxs, const pp_map* const* maps, uint32_t n_ctx,
+                                       const pp_config* conf, uint64_t nq, const double* starts,
+                                       const double* goals, pp_path* out, pp_plan_stats* stats,
+                                       int32_t* status) {
+  if (!ctxs || !maps || n_ctx == 0 || !conf || (nq && (!starts || !goals || !out))) return PP_ERR_INVALID;
+  for (uint32_t k = 0; k < n_ctx; ++k) {
+    if (!ctxs[k] || !maps[k]) return PP_ERR_INVALID;
+    for (uint32_t j = 0; j < k; ++j)
+      if (ctxs[j] == ctxs[k]) return PP_ERR_INVALID;  // a context runs one batch at a time
+  }
+  if (nq == 0) return PP_OK;
+  if (n_ctx == 1) return pp_plan_batch(ctxs[0], maps[0], conf, nq, starts, goals, out, stats, status);
+  if (!(conf->xy_reso > 0.0)) return PP_ERR_INVALID;
+  // order by goal cell, ties by position (queries of one goal keep their order)
+  std::vector<uint64_t> order(nq);
+  std::vector<std::pair<uint64_t, uint64_t>> cell(nq);
+  for (uint64_t i = 0; i < nq; ++i) {
+    order[i] = i;
+    cell[i] = {pp_sat_usize(std::round(goals[3 * i] / conf->xy_reso)),
+               pp_sat_usize(std::round(goals[3 * i + 1] / conf->xy_reso))};
+  }
+  std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return cell[a] < cell[b]; });
+  struct Share {
+    std::vector<uint64_t> ids;
+    std::vector<double> s, g;
+    std::vector<pp_path> paths;
+    std::vector<pp_plan_stats> stats;
+    std::vector<int32_t> status;
+    int32_t ret = PP_OK;
+  };
+  std::vector<Share> sh(n_ctx);
+  for (uint32_t k = 0; k < n_ctx; ++k) {
+    Share& h = sh[k];
+    const uint64_t lo = nq * k / n_ctx, hi = nq * (k + 1) / n_ctx;
+    h.ids.assign(order.begin() + lo, order.begin() + hi);
+    std::sort(h.ids.begin(), h.ids.end());
+    const size_t m = h.ids.size();
+    h.s.resize(3 * m);
+    h.g.resize(3 * m);
+    h.paths.resize(m);
+    h.status.assign(m, PP_OK);
+    if (stats) h.stats.resize(m);
+    for (size_t j = 0; j < m; ++j) {
+      const uint64_t i = h.ids[j];
+      std::memcpy(&h.s[3 * j], &starts[3 * i], 24);
+      std::memcpy(&h.g[3 * j], &goals[3 * i], 24);
+      h.paths[j] = out[i];            // the caller's buffers and capacities
+      if (stats) h.stats[j] = stats[i];  // closed_order / closed_cap are inputs
+    }
+  }
+  std::vector<std::thread> th;
+  for (uint32_t k = 0; k < n_ctx; ++k) {
+    th.emplace_back([&, k] {
+      Share& h = sh[k];
+      if (h.ids.empty()) return;
+      h.ret = pp_plan_batch(ctxs[k], maps[k], conf, h.ids.size(), h.s.data(), h.g.data(), h.paths.data(),
+                            stats ? h.stats.data() : nullptr, h.status.data());
+    });
+  }
+  for (auto& t : th) t.join();
+  int32_t ret = PP_OK;
+  for (uint32_t k = 0; k < n_ctx; ++k) {
+    Share& h = sh[k];
+    if (h.ret != PP_OK && ret == PP_OK) ret = h.ret;  // the batch as a whole failed on that context
+    for (size_t j = 0; j < h.ids.size(); ++j) {
+      const uint64_t i = h.ids[j];
+      out[i].len = h.paths[j].len;
+      out[i].cost = h.paths[j].cost;
+      if (stats) stats[i] = h.stats[j];
+      if (status) status[i] = h.ret == PP_OK ? h.status[j] : h.ret;
+      else if (h.ret == PP_OK && h.status[j] < 0 && ret == PP_OK) ret = h.status[j];
+    }
+  }
+  return ret;
+}

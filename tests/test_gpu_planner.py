@@ -407,6 +407,52 @@ def test_table_budget_does_not_change_a_batch(ctx):
             assert np.array_equal(v, r[k], equal_nan=True), k
 
 
+def test_batch_over_several_contexts_equals_one_context(ctx):
+    """pp_plan_batch_multi deals the queries over contexts (one per device in a multi-GPU process;
+    here three on the one card) by goal group, a host thread each, and gathers every result at its
+    query's place: equal to pp_plan_batch over the whole list, failing and capped queries included."""
+    occ = W.plan_map(1024, 0.02)
+    cs, cg = W.plan_queries(3000, 1024, 9, min_dist=20.0, max_dist=150.0)
+    m = api.ObstacleMap(ctx, raster=occ)
+    fs = api.collision_flags(ctx, m, CONF, cs[:, 0], cs[:, 1], cs[:, 2])
+    fg = api.collision_flags(ctx, m, CONF, cg[:, 0], cg[:, 1], cg[:, 2])
+    inside = (cs[:, 0] > 8) & (cs[:, 0] < 1015) & (cs[:, 1] > 8) & (cs[:, 1] < 1015)
+    keep = np.nonzero(inside & (fs == 0) & (fg == 0))[0][:397]
+    starts, goals = cs[keep].copy(), cg[keep].copy()
+    starts[5] = [-40.0, 20.0, 0.0]      # outside the map: no successor passes the index test, None
+    starts[11] = goals[11]              # start == goal: the Reeds-Shepp assert
+    ctxs = [api.Context(0) for _ in range(3)]
+    maps = [api.ObstacleMap(c, raster=occ) for c in ctxs]
+    keys = ("status", "len", "cost", "x", "y", "yaw", "dir", "closed")
+    try:
+        for c in ctxs + [ctx]:
+            c.set_max_expansions(200)
+            c.set_host_threads(4)
+        one = api.plan_batch(ctx, m, CONF, starts, goals, cap=2048, closed_cap=200)
+        one = {k: np.array(one[k], copy=True) for k in keys} | {"exp": [int(s.expansions) for s in one["stats"]]}
+        many = api.plan_batch(ctxs, maps, CONF, starts, goals, cap=2048, closed_cap=200)
+        for k in keys:
+            assert np.array_equal(one[k], many[k], equal_nan=True), k
+        assert one["exp"] == [int(s.expansions) for s in many["stats"]]
+        seen = set(int(v) for v in one["status"])
+        assert {A.PP_OK, A.PP_NO_PATH, A.PP_ERR_LIMIT, A.PP_ERR_DEGENERATE_RS} <= seen, seen
+        # dealt by goal: a context relaxed about a third of the nine goals' grids, not all of them
+        grids = [api.plan_batch_counters(c)["goal_grids"] for c in ctxs]
+        assert sum(api.plan_batch_counters(c)["queries"] for c in ctxs) == len(starts)
+        assert max(grids) <= 5 and sum(grids) <= 9 + 2 + 2, grids
+        # fewer queries than contexts, and the same context twice
+        few = api.plan_batch(ctxs, maps, CONF, starts[:2], goals[:2], cap=2048, closed_cap=200)
+        assert np.array_equal(few["status"], one["status"][:2]) and np.array_equal(few["cost"], one["cost"][:2], equal_nan=True)
+        with pytest.raises(api.PlannerError) as e:
+            api.plan_batch([ctxs[0], ctxs[0]], maps[:2], CONF, starts[:4], goals[:4])
+        assert e.value.status == A.PP_ERR_INVALID
+    finally:
+        ctx.set_max_expansions(100000)
+        ctx.set_host_threads(15)
+        for o in maps + ctxs:
+            o.close()
+
+
 def test_host_thread_count_does_not_change_a_batch(ctx):
     """pp_ctx_set_host_threads only says how many threads apply a round's results."""
     ox, oy = W.demo_obstacles()

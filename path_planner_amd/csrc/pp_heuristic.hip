@@ -122,6 +122,9 @@ constexpr int kTile = 32;                    // cells per block side (one wave's
 constexpr int kPps = 8;                      // 4x4 patches per block side
 constexpr int kBlk = kTile * kTile;          // doubles per block
 constexpr unsigned long long kInfBits = 0x7FF0000000000000ull;
+#ifndef PP_TILE_WAVES
+#define PP_TILE_WAVES 3      // waves per SIMD the register allocation of k_tile_round aims at
+#endif
 
 // LDS slot of patch cell (i, j); only cells on the patch rim are ever read by other lanes.
 __device__ constexpr int rim_slot(int i, int j) {
@@ -486,9 +489,6 @@ constexpr uint32_t kSweepCap = PP_SWEEP_CAP;  // sweeps per visit (the mean visi
 #ifndef PP_CAP_MIN_TILES
 #define PP_CAP_MIN_TILES 64
 #endif
-#ifndef PP_TILE_WAVES
-#define PP_TILE_WAVES 3                      // waves per SIMD the register allocation of k_tile_round aims at
-#endif
 #ifndef PP_TILE_GRID
 #define PP_TILE_GRID 4                       // workgroups per CU in a round's launch
 #endif
@@ -600,34 +600,46 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
         if (on_rim(i, j)) lds[rim_slot(i, j) * kSSlot + own_slot] = v;
       }
     }
-    // the ring of cells just outside the tile: 66 + 66 + 64 + 64 of them
-    for (int r = (int)tid; r < 2 * (kSTile + 2) + 2 * kSTile; r += 256) {
-      if (r < 2 * (kSTile + 2)) {
-        const int side = r >= kSTile + 2, o = (side ? r - (kSTile + 2) : r) - 1;  // o = -1 .. 64
+    // the ring of cells just outside the tile: 64 on each side, one per thread, and the four corner
+    // cells, which threads 0..3 fetch alongside their side cell (both loads in flight together: a
+    // second pass over the ring for four cells would cost every visit a memory round trip)
+    {
+      const int r = (int)tid;
+      const bool xside = r < 2 * kSTile;
+      const int rr = xside ? r : r - 2 * kSTile;
+      const int side = rr >= kSTile, o = rr & (kSTile - 1);  // o = 0 .. 63
+      bool rel, crel = false;
+      double cv = INF;
+      const int cside = (int)(tid >> 1), co = (tid & 1u) ? kSTile : -1;
+      if (tid < 4) cv = tile_cell_value(g, cside ? X0 + kSTile : X0 - 1, Y0 + co, crel, round);
+      const double v = xside ? tile_cell_value(g, side ? X0 + kSTile : X0 - 1, Y0 + o, rel, round)
+                             : tile_yrim_value(g, X0 + o, side ? Y0 + kSTile : Y0 - 1, rel, round);
+      if (xside) {
         const int q = (o + 4) >> 2, j = (o + 4) & 3;
-        bool rel;
-        const double v = tile_cell_value(g, side ? X0 + kSTile : X0 - 1, Y0 + o, rel, round);
         if (!side)
           lds[(4 + j) * kSSlot + 0 * kSRow + q] = v;                // slot (3, j)
         else
           lds[j * kSSlot + (kSRing - 1) * kSRow + q] = v;           // slot (0, j)
-        const double rv = rel ? v : -1.0;
-        reach[side][o + 1] = rv;
-        // the four corner cells are also the ends of the y sides' rows
-        if (o < 0) reach[2][side ? kSTile + 1 : 0] = rv;
-        if (o >= kSTile) reach[3][side ? kSTile + 1 : 0] = rv;
+        reach[side][o + 1] = rel ? v : -1.0;
       } else {
-        const int rr = r - 2 * (kSTile + 2);
-        const int side = rr >= kSTile, o = side ? rr - kSTile : rr;  // o = 0 .. 63
         const int prow = (o >> 2) + 1, i = o & 3;
         const int s3 = i == 0 ? 3 : (i == 3 ? 7 : 9 + i), s0 = i == 0 ? 0 : (i == 3 ? 4 : 7 + i);
-        bool rel;
-        const double v = tile_yrim_value(g, X0 + o, side ? Y0 + kSTile : Y0 - 1, rel, round);
         if (!side)
           lds[s3 * kSSlot + prow * kSRow + 0] = v;                  // slot (i, 3)
         else
           lds[s0 * kSSlot + prow * kSRow + (kSRing - 1)] = v;       // slot (i, 0)
         reach[2 + side][o + 1] = rel ? v : -1.0;
+      }
+      if (tid < 4) {
+        const int q = (co + 4) >> 2, j = (co + 4) & 3;
+        if (!cside)
+          lds[(4 + j) * kSSlot + 0 * kSRow + q] = cv;
+        else
+          lds[j * kSSlot + (kSRing - 1) * kSRow + q] = cv;
+        const double rv = crel ? cv : -1.0;
+        reach[cside][co + 1] = rv;
+        // the corner cells are also the ends of the y sides' rows
+        reach[co < 0 ? 2 : 3][cside ? kSTile + 1 : 0] = rv;
       }
     }
     __syncthreads();
@@ -648,16 +660,29 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
       bool moved = false;  // values only ever go down
       if (tid == 0) act[(sweeps + 2u) % 3u] = 0;  // last read before the previous barrier, filled after the next
       if (active) {
-#pragma unroll
-        for (int ii = 0; ii < 6; ++ii) {
-#pragma unroll
-          for (int jj = 0; jj < 6; ++jj) {
-            if (ii >= 1 && ii <= 4 && jj >= 1 && jj <= 4) continue;
-            const int dx = ii == 0 ? -1 : (ii == 5 ? 1 : 0), dy = jj == 0 ? -1 : (jj == 5 ? 1 : 0);
-            const int si = ii == 0 ? 3 : (ii == 5 ? 0 : ii - 1), sj = jj == 0 ? 3 : (jj == 5 ? 0 : jj - 1);
-            e[ii][jj] = lds[rim_slot(si, sj) * kSSlot + own_slot + dx * kSRow + dy];
-          }
-        }
+#define PP_FLOOR(v, i, j) pp_max_f64(v, floor_[(i) - 1][(j) - 1])
+        // the cells around the patch, read for the pass that uses them (PASS 0: the forward pass
+        // reads row 0, column 0 and rows 0..3 of column 5; PASS 1: the backward pass the rest and
+        // again what both need, which may have moved on meanwhile -- any mix of old and new is fine).
+        // Eight reads more per sweep than fetching the whole ring once, but twelve values fewer
+        // held across the forward pass (16384^2: 19.1 -> 18.7 ms)
+#ifndef PP_HALO_WHOLE
+#define PP_HALO_WANTED(ii, jj, PASS) ((PASS) == 0 ? ((ii) == 0 || ((jj) == 0 && (ii) <= 4) || ((jj) == 5 && (ii) <= 3)) \
+                                                  : ((ii) == 5 || ((jj) == 5 && (ii) >= 1) || ((jj) == 0 && (ii) >= 2)))
+#else
+#define PP_HALO_WANTED(ii, jj, PASS) ((PASS) == 0)
+#endif
+#define PP_HALO_READ(PASS)                                                                                   \
+  _Pragma("unroll") for (int ii = 0; ii < 6; ++ii) {                                                         \
+    _Pragma("unroll") for (int jj = 0; jj < 6; ++jj) {                                                       \
+      if (ii >= 1 && ii <= 4 && jj >= 1 && jj <= 4) continue;                                                \
+      if (!PP_HALO_WANTED(ii, jj, PASS)) continue;                                                           \
+      const int dx = ii == 0 ? -1 : (ii == 5 ? 1 : 0), dy = jj == 0 ? -1 : (jj == 5 ? 1 : 0);                \
+      const int si = ii == 0 ? 3 : (ii == 5 ? 0 : ii - 1), sj = jj == 0 ? 3 : (jj == 5 ? 0 : jj - 1);        \
+      e[ii][jj] = lds[rim_slot(si, sj) * kSSlot + own_slot + dx * kSRow + dy];                               \
+    }                                                                                                        \
+  }
+        PP_HALO_READ(0)
 #pragma unroll
         for (int i = 1; i <= 4; ++i) {
 #pragma unroll
@@ -667,11 +692,14 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
             v = pp_min_f64(v, e[i - 1][j] + 1.0);
             v = pp_min_f64(v, e[i - 1][j + 1] + diag);
             v = pp_min_f64(v, e[i][j - 1] + 1.0);
-            v = pp_max_f64(v, floor_[i - 1][j - 1]);
+            v = PP_FLOOR(v, i, j);
             moved |= v < e[i][j];
             e[i][j] = v;
           }
         }
+#ifndef PP_HALO_WHOLE
+        PP_HALO_READ(1)
+#endif
 #pragma unroll
         for (int i = 4; i >= 1; --i) {
 #pragma unroll
@@ -681,7 +709,7 @@ k_tile_round(TileGrid g, TileWork w, uint32_t round, double diag) {
             v = pp_min_f64(v, e[i + 1][j] + 1.0);
             v = pp_min_f64(v, e[i + 1][j - 1] + diag);
             v = pp_min_f64(v, e[i][j + 1] + 1.0);
-            v = pp_max_f64(v, floor_[i - 1][j - 1]);
+            v = PP_FLOOR(v, i, j);
             moved |= v < e[i][j];
             e[i][j] = v;
           }

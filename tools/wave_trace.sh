@@ -11,7 +11,7 @@ rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 t0=int(rows[0]["Start_Timestamp"]); prev=None
 for r in rows:
     s,e=int(r["Start_Timestamp"]),int(r["End_Timestamp"])
-    name=r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0]
+    name=r["Kernel_Name"].replace("(anonymous namespace)::","").replace("void ","").split("(")[0].split("<")[0]
     print(f"{name:14s} start {(s-t0)/1e3:10.1f} us dur {(e-s)/1e3:8.1f} gap {((s-prev)/1e3 if prev else 0):6.1f}")
     prev=e
 PY

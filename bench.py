@@ -73,15 +73,17 @@ def parse():
     ap.add_argument("--queries", type=int, default=4096)
     ap.add_argument("--map", type=int, default=4096, help="queries workload map edge")
     ap.add_argument("--goals", type=int, default=64, help="distinct goals the queries share")
-    ap.add_argument("--max-expansions", type=int, default=3000)
+    ap.add_argument("--max-expansions", type=int, default=0,
+                    help="expansion cap per query (default 3000, with --heavy 8000: under 2 %% of its queries end there)")
     ap.add_argument("--deal", default="goal", choices=["goal", "roundrobin"],
                     help="queries workload with several ranks: a rank gets whole goal groups (it then relaxes only "
                          "its goals' heuristic grids) or every rank-th query of the list")
     ap.add_argument("--weak", action="store_true",
                     help="queries workload: --queries is the count per rank (weak scaling) instead of the total")
     ap.add_argument("--heavy", action="store_true",
-                    help="queries workload: obstacle density 0.035 and starts 100-400 m from the goal "
-                         "(the median query closes about a hundred nodes)")
+                    help="queries workload: obstacle density 0.025 and starts 100-400 m from the goal "
+                         "(the median query closes 74 nodes, 1.5 M nodes in all)")
+    ap.add_argument("--heavy-density", type=float, default=0.025, help="obstacle density of the --heavy map")
     ap.add_argument("--band", type=float, default=0.0, help="relaxation band override (wavefront)")
     ap.add_argument("--slab-band", type=float, default=1024.0,
                     help="multi-GPU wavefront: cost band the ranks advance by per exchange round")
@@ -378,10 +380,11 @@ def wl_wavefront(args, E):
 
 def wl_queries(args, E):
     api, W, A = E.api, E.W, E.A
-    dens, dmin, dmax = (0.035, 100.0, 400.0) if args.heavy else (0.006, 30.0, 200.0)
+    dens, dmin, dmax = (args.heavy_density, 100.0, 400.0) if args.heavy else (0.006, 30.0, 200.0)
+    max_exp = args.max_expansions or (8000 if args.heavy else 3000)
     occ = W.plan_map(args.map, dens)
     omap = api.ObstacleMap(E.ctx, raster=occ)
-    E.ctx.set_max_expansions(args.max_expansions)
+    E.ctx.set_max_expansions(max_exp)
     # candidates whose start or goal pose collides are dropped (device check), then the
     # first --queries survivors are dealt round-robin to the ranks
     total = args.queries * (E.world if args.weak else 1)
@@ -404,7 +407,7 @@ def wl_queries(args, E):
         bound="latency", counters_key=None,
         config={"workload": f"{total} hybrid A* queries on a {args.map}x{args.map} map (border + "
                             f"clustered wall segments, density {occ.mean():.4f}), {args.goals} shared goals, "
-                            f"start {dmin:.0f}-{dmax:.0f} m from goal, expansion cap {args.max_expansions}",
+                            f"start {dmin:.0f}-{dmax:.0f} m from goal, expansion cap {max_exp}",
                 "queries": total, "variant": "search-heavy" if args.heavy else "light",
                 "parallelism": f"query-sharded x{E.world}",
                 "deal": ("whole goal groups per rank" if args.deal == "goal" else "round-robin") if E.world > 1 else None})
@@ -444,10 +447,10 @@ def wl_queries(args, E):
 
     def cpu(O):
         from concurrent.futures import ThreadPoolExecutor
-        nt = args.cpu_sample or 32     # timed one after the other on one core
+        nt = args.cpu_sample or (16 if args.heavy else 32)  # timed one after the other on one core (10-20 s)
         nc = 64                        # checked against the device result (the rest on a thread pool)
         om = O.OracleMap(*W.raster_to_points(occ))
-        O.set_max_expansions(args.max_expansions)
+        O.set_max_expansions(max_exp)
         r = last["r"]
 
         def differs(i, e):

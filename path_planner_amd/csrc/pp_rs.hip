@@ -68,18 +68,27 @@ __device__ inline void write_word(pp_rs_word* o, uint32_t word, int n, const dou
 
 // Two waves per SIMD measured best for this register-hungry kernel (1.68 G pairs/s; the compiler's
 // own choice of one wave gives 1.1, three waves spill and give 1.4, four 0.97).
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#ifndef PP_RS_BATCH_WAVES
+#define PP_RS_BATCH_WAVES 2
+#endif
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(PP_RS_BATCH_WAVES, PP_RS_BATCH_WAVES)))
 k_rs_batch(uint64_t n, const double* __restrict__ sx, const double* __restrict__ sy,
            const double* __restrict__ syaw, const double* __restrict__ gx,
            const double* __restrict__ gy, const double* __restrict__ gyaw, double maxc,
            int32_t* __restrict__ n_paths, int32_t* __restrict__ best_idx,
            pp_rs_word* __restrict__ best, uint8_t* __restrict__ flags) {
+  // the lane's sixteen polar forms (pp_polar_fill): 256 bytes a lane, the doubles of one kind side by side
+  __shared__ double polar[32 * 128];
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     PpRsState S;
     BestSink sink;
     sink.maxc = maxc;
-    pp_rs_generate(sx[i], sy[i], syaw[i], gx[i], gy[i], gyaw[i], maxc, S, sink);
+    const PpRsInput in = pp_rs_input(sx[i], sy[i], syaw[i], gx[i], gy[i], gyaw[i], maxc);
+    pp_polar_fill(in, polar + threadIdx.x, 128);
+    S.polar = polar + threadIdx.x;  // only this lane reads what it wrote: no barrier
+    S.polar_stride = 128;
+    pp_rs_generate_compact(in, S, sink);
     int np = __popcll(S.accepted);
     if (S.degenerate) {  // the reference panics inside generate_path: no paths reported
       n_paths[i] = 0;

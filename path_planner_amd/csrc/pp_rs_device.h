@@ -27,6 +27,25 @@ struct PpTuv {
   double t, u, v;
 };
 
+// The inverse trigonometric functions as real calls: each inlined copy brings two dozen 64-bit
+// polynomial coefficients with it, which the compiler hoists out of every enclosing loop and then
+// has to keep in registers across the loop's whole body.
+#ifndef PP_RS_MATH_INLINE
+#define PP_RS_MATH_ATTR __noinline__
+#else
+#define PP_RS_MATH_ATTR __forceinline__
+#endif
+__device__ PP_RS_MATH_ATTR double pp_atan2(double y, double x) { return atan2(y, x); }
+__device__ PP_RS_MATH_ATTR double pp_asin(double x) { return asin(x); }
+__device__ PP_RS_MATH_ATTR double pp_acos(double x) { return acos(x); }
+__device__ PP_RS_MATH_ATTR double pp_tan(double x) { return tan(x); }
+__device__ PP_RS_MATH_ATTR double pp_cos(double x) { return cos(x); }
+__device__ PP_RS_MATH_ATTR double2 pp_sincos(double x) {
+  double s, c;
+  sincos(x, &s, &c);
+  return make_double2(s, c);
+}
+
 // Accumulates "a comparison was decided inside the guard band".
 struct PpAmb {
   bool amb;
@@ -36,12 +55,37 @@ struct PpAmb {
   __device__ __forceinline__ bool lt(double a, double b) { amb |= fabs(a - b) < PP_RS_GUARD; return a < b; }
 };
 
-// reeds_shepp.rs:747-757
+// reeds_shepp.rs:747-757.  `theta % (2 pi)` is exact (the remainder of a division by the double
+// 2 pi is always representable), and so is one fused multiply-add with the truncated quotient; a
+// quotient that comes out one off near a multiple of 2 pi leaves a remainder just below zero
+// instead of just below 2 pi, which the wrap below maps to the same value (x - 2 pi is exact there).
 __device__ __forceinline__ double pp_mod2pi(double theta, PpAmb& A) {
-  double phi = fmod(theta, 2.0 * PP_RS_PI);
-  if (A.lt(phi, -PP_RS_PI)) phi += 2.0 * PP_RS_PI;
-  if (A.gt(phi, PP_RS_PI)) phi -= 2.0 * PP_RS_PI;
+  const double c = 2.0 * PP_RS_PI;
+  double phi;
+  if (fabs(theta) < 1.0e6) {
+    const double q = trunc(theta * (1.0 / (2.0 * PP_RS_PI)));
+    phi = __builtin_fma(-q, c, theta);
+  } else {
+    phi = fmod(theta, c);
+  }
+  if (A.lt(phi, -PP_RS_PI)) phi += c;
+  if (A.gt(phi, PP_RS_PI)) phi -= c;
   return phi;
+}
+
+// Polar form (reeds_shepp.rs:740-745) of one of the two points the formulas measure from:
+//   set 0: (x - sin phi, y - 1 + cos phi)   lsl, lrl, lrsl
+//   set 1: (x + sin phi, y - 1 - cos phi)   lsr, lrlrn, lrlrp, lrsr, lrslr
+// Eight formulas share two points per mirror image, so a caller that evaluates all of them can
+// compute the sixteen polar forms of a pair (four images, forward and backwards point) once.
+struct PpPolar {
+  double rho, th;
+};
+__device__ __forceinline__ PpPolar pp_polar(double px, double py) {
+  return PpPolar{sqrt(px * px + py * py), pp_atan2(py, px)};
+}
+__device__ __forceinline__ PpPolar pp_polar_set(double x, double y, double sp, double cp, int set) {
+  return set ? pp_polar(x + sp, y - 1.0 - cp) : pp_polar(x - sp, y - 1.0 + cp);
 }
 // reeds_shepp.rs:727-738
 __device__ __forceinline__ double pp_pi_2_pi(double theta) {
@@ -59,7 +103,7 @@ __device__ __forceinline__ PpTuv pp_f_sls(double x, double y, double phi, PpAmb&
   bool pos = A.gt(y, 0.), neg = A.lt(y, 0.);
   bool rng = A.lt(0., p) & A.lt(p, PP_RS_PI * 0.99);
   if ((pos | neg) & rng) {
-    double tp = tan(p), th = tan(p / 2.);
+    double tp = pp_tan(p), th = pp_tan(p / 2.);
     double xd = -y / tp + x;
     double t = xd - th;
     double rt = sqrt((x - xd) * (x - xd) + y * y);
@@ -69,10 +113,9 @@ __device__ __forceinline__ PpTuv pp_f_sls(double x, double y, double phi, PpAmb&
   return r;
 }
 // :161-170
-__device__ __forceinline__ PpTuv pp_f_lsl(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+__device__ __forceinline__ PpTuv pp_f_lsl(double phi, const PpPolar& p0, PpAmb& A) {
   PpTuv r{false, 0., 0., 0.};
-  double ax = x - sp, ay = y - 1.0 + cp;
-  double u = hypot(ax, ay), t = atan2(ay, ax);
+  double u = p0.rho, t = p0.th;
   if (A.ge(t, 0.0)) {
     double v = pp_mod2pi(phi - t, A);
     if (A.ge(v, 0.0)) r = PpTuv{true, t, u, v};
@@ -80,14 +123,13 @@ __device__ __forceinline__ PpTuv pp_f_lsl(double x, double y, double phi, double
   return r;
 }
 // :172-186
-__device__ __forceinline__ PpTuv pp_f_lsr(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+__device__ __forceinline__ PpTuv pp_f_lsr(double phi, const PpPolar& p1, PpAmb& A) {
   PpTuv r{false, 0., 0., 0.};
-  double ax = x + sp, ay = y - 1.0 - cp;
-  double u1 = hypot(ax, ay), t1 = atan2(ay, ax);
+  double u1 = p1.rho, t1 = p1.th;
   u1 = u1 * u1;
   if (A.ge(u1, 4.)) {
     double u = sqrt(u1 - 4.);
-    double theta = atan2(2.0, u);
+    double theta = pp_atan2(2.0, u);
     double t = pp_mod2pi(t1 + theta, A);
     double v = pp_mod2pi(t - phi, A);
     if (A.ge(t, 0.) & A.ge(v, 0.0)) r = PpTuv{true, t, u, v};
@@ -95,12 +137,11 @@ __device__ __forceinline__ PpTuv pp_f_lsr(double x, double y, double phi, double
   return r;
 }
 // :188-200
-__device__ __forceinline__ PpTuv pp_f_lrl(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+__device__ __forceinline__ PpTuv pp_f_lrl(double phi, const PpPolar& p0, PpAmb& A) {
   PpTuv r{false, 0., 0., 0.};
-  double ax = x - sp, ay = y - 1.0 + cp;
-  double u1 = hypot(ax, ay), t1 = atan2(ay, ax);
+  double u1 = p0.rho, t1 = p0.th;
   if (A.le(u1, 4.)) {
-    double u = -2. * asin(0.25 * u1);
+    double u = -2. * pp_asin(0.25 * u1);
     double t = pp_mod2pi(t1 + 0.5 * u + PP_RS_PI, A);
     double v = pp_mod2pi(phi - t + u, A);
     if (A.ge(t, 0.) & A.le(u, 0.0)) r = PpTuv{true, t, u, v};
@@ -111,23 +152,23 @@ __device__ __forceinline__ PpTuv pp_f_lrl(double x, double y, double phi, double
 __device__ __forceinline__ void pp_tau_omega(double u, double v, double xi, double eta, double phi,
                                              double& tau, double& omega, PpAmb& A) {
   double delta = pp_mod2pi(u - v, A);
-  double su, cu, sd, cd;
-  sincos(u, &su, &cu);
-  sincos(delta, &sd, &cd);
+  const double2 scu = pp_sincos(u), scd = pp_sincos(delta);
+  const double su = scu.x, cu = scu.y, sd = scd.x, cd = scd.y;
   double a = su - sd;
   double b = cu - cd - 1.0;
-  double t1 = atan2(eta * a - xi * b, xi * a + eta * b);
-  double t2 = 2.0 * (cd - cos(v) - cu) + 3.0;
+  double t1 = pp_atan2(eta * a - xi * b, xi * a + eta * b);
+  double t2 = 2.0 * (cd - pp_cos(v) - cu) + 3.0;
   tau = A.lt(t2, 0.) ? pp_mod2pi(t1 + PP_RS_PI, A) : pp_mod2pi(t1, A);
   omega = pp_mod2pi(tau - u + v - phi, A);
 }
 // :334-347
-__device__ __forceinline__ PpTuv pp_f_lrlrn(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+__device__ __forceinline__ PpTuv pp_f_lrlrn(double x, double y, double phi, double sp, double cp, const PpPolar& p1,
+                                            PpAmb& A) {
   PpTuv r{false, 0., 0., 0.};
   double xi = x + sp, eta = y - 1.0 - cp;
-  double rho = 0.25 * (2.0 + sqrt(xi * xi + eta * eta));
+  double rho = 0.25 * (2.0 + p1.rho);
   if (A.le(rho, 1.0)) {
-    double u = acos(rho), t, v;
+    double u = pp_acos(rho), t, v;
     pp_tau_omega(u, -u, xi, eta, phi, t, v, A);
     if (A.ge(t, 0.) & A.le(v, 0.)) r = PpTuv{true, t, u, v};
   }
@@ -139,7 +180,7 @@ __device__ __forceinline__ PpTuv pp_f_lrlrp(double x, double y, double phi, doub
   double xi = x + sp, eta = y - 1.0 - cp;
   double rho = (20. - xi * xi - eta * eta) / 16.0;
   if (A.le(0.0, rho) & A.le(rho, 1.0)) {
-    double u = -acos(rho);
+    double u = -pp_acos(rho);
     if (A.ge(u, -0.5 * PP_RS_PI)) {
       double t, v;
       pp_tau_omega(u, u, xi, eta, phi, t, v, A);
@@ -149,10 +190,11 @@ __device__ __forceinline__ PpTuv pp_f_lrlrp(double x, double y, double phi, doub
   return r;
 }
 // :408-422
-__device__ __forceinline__ PpTuv pp_f_lrsr(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+__device__ __forceinline__ PpTuv pp_f_lrsr(double phi, const PpPolar& p1, PpAmb& A) {
   PpTuv r{false, 0., 0., 0.};
-  double xi = x + sp, eta = y - 1.0 - cp;
-  double rho = hypot(-eta, xi), theta = atan2(xi, -eta);
+  // r(-eta, xi): the point (xi, eta) turned by a quarter, so its angle plus pi / 2, back in (-pi, pi]
+  double rho = p1.rho, theta = p1.th + 0.5 * PP_RS_PI;
+  if (theta > PP_RS_PI) theta -= 2.0 * PP_RS_PI;
   if (A.ge(rho, 2.0)) {
     double t = theta;
     double u = 2.0 - rho;
@@ -162,28 +204,28 @@ __device__ __forceinline__ PpTuv pp_f_lrsr(double x, double y, double phi, doubl
   return r;
 }
 // :423-438
-__device__ __forceinline__ PpTuv pp_f_lrsl(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+__device__ __forceinline__ PpTuv pp_f_lrsl(double phi, const PpPolar& p0, PpAmb& A) {
   PpTuv r{false, 0., 0., 0.};
-  double xi = x - sp, eta = y - 1.0 + cp;
-  double rho = hypot(xi, eta), theta = atan2(eta, xi);
+  double rho = p0.rho, theta = p0.th;
   if (A.ge(rho, 2.0)) {
     double rr = sqrt(rho * rho - 4.0);
     double u = 2.0 - rr;
-    double t = pp_mod2pi(theta + atan2(rr, -2.0), A);
+    double t = pp_mod2pi(theta + pp_atan2(rr, -2.0), A);
     double v = pp_mod2pi(phi - 0.5 * PP_RS_PI - t, A);
     if (A.ge(t, 0.0) & A.le(u, 0.0) & A.le(v, 0.0)) r = PpTuv{true, t, u, v};
   }
   return r;
 }
 // :526-542
-__device__ __forceinline__ PpTuv pp_f_lrslr(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+__device__ __forceinline__ PpTuv pp_f_lrslr(double x, double y, double phi, double sp, double cp, const PpPolar& p1,
+                                            PpAmb& A) {
   PpTuv r{false, 0., 0., 0.};
   double xi = x + sp, eta = y - 1.0 - cp;
-  double rho = hypot(xi, eta);
+  double rho = p1.rho;
   if (A.ge(rho, 2.0)) {
     double u = 4.0 - sqrt(rho * rho - 4.0);
     if (A.le(u, 0.)) {
-      double t = pp_mod2pi(atan2((4.0 - u) * xi - 2.0 * eta, -2.0 * xi + (u - 4.0) * eta), A);
+      double t = pp_mod2pi(pp_atan2((4.0 - u) * xi - 2.0 * eta, -2.0 * xi + (u - 4.0) * eta), A);
       double v = pp_mod2pi(t - phi, A);
       if (A.ge(t, 0.0) & A.ge(v, 0.0)) r = PpTuv{true, t, u, v};
     }
@@ -228,6 +270,10 @@ struct PpRsState {
   PpAmb A{false};
   bool degenerate = false;  // assert!(total_length >= 0.01) would fire (:157)
   uint64_t accepted = 0;    // bit i: candidate with generation index i became a path
+  // optional: the pair's sixteen polar forms, computed ahead by pp_polar_fill: entry
+  // e = ((back ? 4 : 0) + image) * 2 + set has rho at polar[2 e * polar_stride], theta one stride on
+  const double* polar = nullptr;
+  uint32_t polar_stride = 0;
 };
 
 // set_path, :130-159, for one candidate of word set `ws`.
@@ -269,17 +315,24 @@ struct PpRsInput {
   double x, y, phi, sp, cp, xb, yb;
 };
 
+// The point a formula measures from (pp_polar_set): -1 none, 0 or 1.
 template <int F>
-__device__ __forceinline__ PpTuv pp_eval(double x, double y, double phi, double sp, double cp, PpAmb& A) {
+__host__ __device__ constexpr int pp_formula_set() {
+  return F == PP_F_SLS_ || F == PP_F_LRLRP_ ? -1 : ((F == PP_F_LSL_ || F == PP_F_LRL_ || F == PP_F_LRSL_) ? 0 : 1);
+}
+
+template <int F>
+__device__ __forceinline__ PpTuv pp_eval(double x, double y, double phi, double sp, double cp, const PpPolar& pol,
+                                         PpAmb& A) {
   if (F == PP_F_SLS_) return pp_f_sls(x, y, phi, A);
-  if (F == PP_F_LSL_) return pp_f_lsl(x, y, phi, sp, cp, A);
-  if (F == PP_F_LSR_) return pp_f_lsr(x, y, phi, sp, cp, A);
-  if (F == PP_F_LRL_) return pp_f_lrl(x, y, phi, sp, cp, A);
-  if (F == PP_F_LRLRN_) return pp_f_lrlrn(x, y, phi, sp, cp, A);
+  if (F == PP_F_LSL_) return pp_f_lsl(phi, pol, A);
+  if (F == PP_F_LSR_) return pp_f_lsr(phi, pol, A);
+  if (F == PP_F_LRL_) return pp_f_lrl(phi, pol, A);
+  if (F == PP_F_LRLRN_) return pp_f_lrlrn(x, y, phi, sp, cp, pol, A);
   if (F == PP_F_LRLRP_) return pp_f_lrlrp(x, y, phi, sp, cp, A);
-  if (F == PP_F_LRSL_) return pp_f_lrsl(x, y, phi, sp, cp, A);
-  if (F == PP_F_LRSR_) return pp_f_lrsr(x, y, phi, sp, cp, A);
-  return pp_f_lrslr(x, y, phi, sp, cp, A);
+  if (F == PP_F_LRSL_) return pp_f_lrsl(phi, pol, A);
+  if (F == PP_F_LRSR_) return pp_f_lrsr(phi, pol, A);
+  return pp_f_lrslr(x, y, phi, sp, cp, pol, A);
 }
 
 // One candidate: formula F on mirror image K of the (optionally backwards) point, laid out by
@@ -293,7 +346,18 @@ __device__ __forceinline__ void pp_candidate(PpRsState& S, const PpRsInput& in, 
   const bool negphi = (K == 1 || K == 2);
   const double ap = negphi ? -in.phi : in.phi;
   const double sp = negphi ? -in.sp : in.sp;
-  PpTuv r = pp_eval<F>(ax, ay, ap, sp, in.cp, S.A);
+  PpPolar pol{0.0, 0.0};
+  constexpr int SET = pp_formula_set<F>();
+  if constexpr (SET >= 0) {
+    if (S.polar) {
+      constexpr int e = ((BACK ? 4 : 0) + K) * 2 + SET;
+      pol.rho = S.polar[(size_t)(2 * e) * S.polar_stride];
+      pol.th = S.polar[(size_t)(2 * e + 1) * S.polar_stride];
+    } else {
+      pol = pp_polar_set(ax, ay, sp, in.cp, SET);
+    }
+  }
+  PpTuv r = pp_eval<F>(ax, ay, ap, sp, in.cp, pol, S.A);
   if (!r.ok) return;
   const double H = 0.5 * PP_RS_PI;
   double len[N];
@@ -334,6 +398,21 @@ __device__ __forceinline__ PpRsInput pp_rs_input(double sx, double sy, double sy
   in.xb = in.x * in.cp + in.y * in.sp;  // :294-295, :482-483
   in.yb = in.x * in.sp - in.y * in.cp;
   return in;
+}
+
+// The sixteen polar forms of a pair, stored `stride` doubles apart (see PpRsState::polar): straight
+// line code, every lane busy, instead of thirty-six hypot / atan2 pairs inside the formulas' branches.
+__device__ __forceinline__ void pp_polar_fill(const PpRsInput& in, double* out, uint32_t stride) {
+#pragma unroll 2
+  for (int e = 0; e < 16; ++e) {
+    const int set = e & 1, K = (e >> 1) & 3, back = e >> 3;
+    const double bx = back ? in.xb : in.x, by = back ? in.yb : in.y;
+    const double ax = (K & 1) ? -bx : bx, ay = (K & 2) ? -by : by;
+    const double sp = (K == 1 || K == 2) ? -in.sp : in.sp;
+    const PpPolar p = pp_polar_set(ax, ay, sp, in.cp, set);
+    out[(size_t)(2 * e) * stride] = p.rho;
+    out[(size_t)(2 * e + 1) * stride] = p.th;
+  }
 }
 
 // The 46 candidates fall into seven families whose duplicate tests (set_path compares only paths
@@ -456,7 +535,10 @@ __device__ __forceinline__ void pp_eval_image(const PpRsInput& in, int K, uint32
   const bool negphi = (K == 1 || K == 2);
   const double ap = negphi ? -in.phi : in.phi;
   const double sp = negphi ? -in.sp : in.sp;
-  const PpTuv r = pp_eval<F>(ax, ay, ap, sp, in.cp, A);
+  PpPolar pol{0.0, 0.0};
+  constexpr int SET = pp_formula_set<F>();
+  if constexpr (SET >= 0) pol = pp_polar_set(ax, ay, sp, in.cp, SET);
+  const PpTuv r = pp_eval<F>(ax, ay, ap, sp, in.cp, pol, A);
   out.nseg = 0;
   if (!r.ok) return;
   const double H = 0.5 * PP_RS_PI;
@@ -550,11 +632,103 @@ __device__ __forceinline__ unsigned long long pp_rs_commit_set(int ws, const PpR
   return acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same 46 candidates with the reflection as a run-time loop: two copies of each formula's code
+// instead of four (the fully unrolled form is a quarter of a megabyte of instructions).  The
+// reflected half (images 2 and 3) is the unreflected half run on (x, -y, -phi) with L and R
+// swapped, and image K + 1 is image K with x and phi negated and the lengths' signs flipped; a
+// word set lives across the two images of a pair (and across the two formulas that share a word),
+// exactly as in pp_rs_group.
+template <int F, bool BACK, int LAY, int N, class Sink>
+__device__ __forceinline__ void pp_candidate_rt(PpRsState& S, const PpRsInput& in, PpWordSet<N>& ws, int K,
+                                                int gen, uint32_t word_k0, Sink& sink) {
+  const double bx = BACK ? in.xb : in.x, by = BACK ? in.yb : in.y;
+  const double ax = (K & 1) ? -bx : bx;
+  const double ay = (K & 2) ? -by : by;
+  const bool negphi = (K == 1 || K == 2);
+  const double ap = negphi ? -in.phi : in.phi;
+  const double sp = negphi ? -in.sp : in.sp;
+  PpPolar pol{0.0, 0.0};
+  constexpr int SET = pp_formula_set<F>();
+  if constexpr (SET >= 0) {
+    const int e = ((BACK ? 4 : 0) + K) * 2 + SET;
+    pol.rho = S.polar[(size_t)(2 * e) * S.polar_stride];
+    pol.th = S.polar[(size_t)(2 * e + 1) * S.polar_stride];
+  }
+  PpTuv r = pp_eval<F>(ax, ay, ap, sp, in.cp, pol, S.A);
+  if (!r.ok) return;
+  const double H = 0.5 * PP_RS_PI;
+  double len[N];
+  if constexpr (LAY == PP_TUV) { len[0] = r.t; len[1] = r.u; len[2] = r.v; }
+  if constexpr (LAY == PP_VUT) { len[0] = r.v; len[1] = r.u; len[2] = r.t; }
+  if constexpr (LAY == PP_T_U_NU_V) { len[0] = r.t; len[1] = r.u; len[2] = -r.u; len[3] = r.v; }
+  if constexpr (LAY == PP_T_U_U_V) { len[0] = r.t; len[1] = r.u; len[2] = r.u; len[3] = r.v; }
+  if constexpr (LAY == PP_T_H_U_V) { len[0] = r.t; len[1] = -H; len[2] = r.u; len[3] = r.v; }
+  if constexpr (LAY == PP_V_U_H_T) { len[0] = r.v; len[1] = r.u; len[2] = -H; len[3] = r.t; }
+  if constexpr (LAY == PP_T_H_U_H_V) { len[0] = r.t; len[1] = -H; len[2] = r.u; len[3] = -H; len[4] = r.v; }
+  if (K & 1) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) len[i] = -len[i];
+  }
+  const uint32_t word = (K & 2) ? pp_word_reflect(word_k0) : word_k0;
+  pp_set_path<N>(S, ws, len, gen, word, sink);
+}
+
+// Images 2h and 2h + 1 of one formula, offered to one word set.
+template <int F, bool BACK, int LAY, int N, class Sink>
+__device__ __forceinline__ void pp_pair_rt(PpRsState& S, const PpRsInput& in, PpWordSet<N>& ws, int h, int gen0,
+                                           uint32_t word_k0, Sink& sink) {
+  // unrolled: as a loop the two images keep every word set of the enclosing block in registers at
+  // once (a few hundred spilled registers, 0.63 -> 0.82 ms per million pairs)
+#pragma unroll
+  for (int f = 0; f < 2; ++f) pp_candidate_rt<F, BACK, LAY, N>(S, in, ws, 2 * h + f, gen0 + 2 * h + f, word_k0, sink);
+}
+
+// generate_path with S.polar filled in (pp_polar_fill); candidates reach the sink word by word,
+// not in generation order.
+template <class Sink>
+__device__ __forceinline__ void pp_rs_generate_compact(const PpRsInput& in, PpRsState& S, Sink& sink) {
+#pragma clang loop unroll(disable)
+  for (int h = 0; h < 2; ++h) {
+    {  // scs :202-211 -- generation indices 0 (image 0) and 1 (image 2)
+      PpWordSet<3> a;
+      pp_candidate_rt<PP_F_SLS_, false, PP_TUV, 3>(S, in, a, 2 * h, h, pp_word("SLS"), sink);
+    }
+    {  // csc :231-270 -- 2..5, 6..9
+      PpWordSet<3> a, c;
+      pp_pair_rt<PP_F_LSL_, false, PP_TUV, 3>(S, in, a, h, 2, pp_word("LSL"), sink);
+      pp_pair_rt<PP_F_LSR_, false, PP_TUV, 3>(S, in, c, h, 6, pp_word("LSR"), sink);
+    }
+    {  // ccc :272-316 -- LRL / RLR collect four candidates each (10, 11, 14, 15 / 12, 13, 16, 17)
+      PpWordSet<3> a;
+      pp_pair_rt<PP_F_LRL_, false, PP_TUV, 3>(S, in, a, h, 10, pp_word("LRL"), sink);
+      pp_pair_rt<PP_F_LRL_, true, PP_VUT, 3>(S, in, a, h, 14, pp_word("LRL"), sink);
+    }
+    {  // cccc :366-406 -- LRLR / RLRL (18, 19, 22, 23 / 20, 21, 24, 25)
+      PpWordSet<4> a;
+      pp_pair_rt<PP_F_LRLRN_, false, PP_T_U_NU_V, 4>(S, in, a, h, 18, pp_word("LRLR"), sink);
+      pp_pair_rt<PP_F_LRLRP_, false, PP_T_U_U_V, 4>(S, in, a, h, 22, pp_word("LRLR"), sink);
+    }
+    {  // ccsc :440-524 -- 26..29, 30..33, and on the backwards point 34..37, 38..41
+      PpWordSet<4> a, c;
+      pp_pair_rt<PP_F_LRSL_, false, PP_T_H_U_V, 4>(S, in, a, h, 26, pp_word("LRSL"), sink);
+      pp_pair_rt<PP_F_LRSR_, false, PP_T_H_U_V, 4>(S, in, c, h, 30, pp_word("LRSR"), sink);
+    }
+    {
+      PpWordSet<4> a, c;
+      pp_pair_rt<PP_F_LRSL_, true, PP_V_U_H_T, 4>(S, in, a, h, 34, pp_word("LSRL"), sink);
+      pp_pair_rt<PP_F_LRSR_, true, PP_V_U_H_T, 4>(S, in, c, h, 38, pp_word("RSRL"), sink);
+    }
+    {  // ccscc :544-580 -- 42..45
+      PpWordSet<5> a;
+      pp_pair_rt<PP_F_LRSLR_, false, PP_T_H_U_H_V, 5>(S, in, a, h, 42, pp_word("LRSLR"), sink);
+    }
+  }
+}
+
 // generate_path, :707-725: the families in the reference's order.
 template <class Sink>
-__device__ __forceinline__ void pp_rs_generate(double sx, double sy, double syaw, double gx, double gy,
-                                               double gyaw, double maxc, PpRsState& S, Sink& sink) {
-  const PpRsInput in = pp_rs_input(sx, sy, syaw, gx, gy, gyaw, maxc);
+__device__ __forceinline__ void pp_rs_generate(const PpRsInput& in, PpRsState& S, Sink& sink) {
   pp_rs_family<0>(in, S, sink);
   pp_rs_family<1>(in, S, sink);
   pp_rs_family<2>(in, S, sink);

@@ -64,21 +64,9 @@ for r in range(rounds):
     npair = 150000
     q0, q1 = W.rs_pairs(npair, seed=seed + 2, extent=float(rng.choice([20.0, 100.0, 400.0])))
     maxc = W.demo_maxc() * float(rng.choice([0.5, 1.0, 2.0]))
-    npaths, best, words, flags = api.rs_batch(ctx, q0, q1, maxc)
-    st, enp, ebest, ewords, eflags = O.rs_batch(q0, q1, maxc, threads=8)
-    ok = (flags & 10) == 0   # neither an accept / duplicate test in the guard band nor a tie at the minimum
-    assert ((flags & 1) == (eflags & 1)).all()
-    gl, gt, gc, gn = O.words_to_numpy(words, npair)
-    el, et, ec, en = O.words_to_numpy(ewords, npair)
-    assert np.allclose(gt, et, rtol=1e-9, atol=0)
-    assert (npaths[ok] == enp[ok]).all() and (best[ok] == ebest[ok]).all()
-    assert (gc[ok] == ec[ok]).all() and (gn[ok] == en[ok]).all()
-    assert np.allclose(gl[ok], el[ok], rtol=1e-9, atol=1e-9)
-    bad = np.nonzero(~ok)[0]
-    assert (np.abs(npaths[bad] - enp[bad]) <= 1).all()
-    for i in bad[::64]:
-        TR.check_flagged_pair(ctx, q0[i], q1[i], maxc, npaths[i], words[i])
-    say(f"round {r}: rs_batch {npair} pairs maxc {maxc:.4f}: unflagged equal, {len(bad)} flagged within bounds")
+    shares = TR.check_batch_against_oracle(ctx, q0, q1, maxc, 0.02, f"soak round {r}")
+    say(f"round {r}: rs_batch {npair} pairs maxc {maxc:.4f}: clean pairs equal, tie-only pairs list the oracle's words, "
+        f"shares {shares}")
 
     # ---- heuristic grid: ragged shapes, bitwise
     xw, yw = int(rng.integers(40, 1500)), int(rng.integers(40, 1500))

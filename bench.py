@@ -78,6 +78,11 @@ def parse():
     ap.add_argument("--deal", default="goal", choices=["goal", "roundrobin"],
                     help="queries workload with several ranks: a rank gets whole goal groups (it then relaxes only "
                          "its goals' heuristic grids) or every rank-th query of the list")
+    ap.add_argument("--contexts", type=int, default=0,
+                    help="queries workload: contexts (stream + host threads each) per GPU that share a rank's "
+                         "queries through pp_plan_batch_multi, so that the latency-bound rounds of one overlap the "
+                         "others' (default: 1 = plain pp_plan_batch; with --heavy 4, where the host side of a round is the bottleneck "
+                         "and four smaller batches keep their tables in cache better than one)")
     ap.add_argument("--weak", action="store_true",
                     help="queries workload: --queries is the count per rank (weak scaling) instead of the total")
     ap.add_argument("--heavy", action="store_true",
@@ -412,9 +417,21 @@ def wl_queries(args, E):
                 "parallelism": f"query-sharded x{E.world}",
                 "deal": ("whole goal groups per rank" if args.deal == "goal" else "round-robin") if E.world > 1 else None})
     last = {}
+    K = args.contexts if args.contexts > 0 else (4 if args.heavy else 1)
+    wl.config["contexts_per_gpu"] = K
+    if K > 1:
+        base_threads = E.host_threads
+        ctxs = [E.ctx] + [api.Context(E.ctx.device) for _ in range(K - 1)]
+        maps = [omap] + [api.ObstacleMap(c, raster=occ) for c in ctxs[1:]]
+        for c in ctxs:
+            c.set_max_expansions(max_exp)
+            c.set_host_threads(max(1, base_threads // K))
 
     def step():
-        last["r"] = api.plan_batch(E.ctx, omap, E.conf, starts, goals, cap=4096, out=last.get("r"))
+        if K > 1:
+            last["r"] = api.plan_batch(ctxs, maps, E.conf, starts, goals, cap=4096, out=last.get("r"))
+        else:
+            last["r"] = api.plan_batch(E.ctx, omap, E.conf, starts, goals, cap=4096, out=last.get("r"))
     wl.step = step
 
     def finish(out):
@@ -435,8 +452,14 @@ def wl_queries(args, E):
             "note": "counters of rank 0's shard, last step"}
         # what sets the time of a lock-step batch, per rank: the grids it relaxes, its rounds (and how many of
         # them ran with the chip nearly empty) and its longest query
-        mine_c = dict(api.plan_batch_counters(E.ctx), t_heuristic_ms=float(stt[0].t_heuristic_ms),
-                      t_search_ms=float(stt[0].t_search_ms), cap_reached=int((r["status"] == A.PP_ERR_LIMIT).sum()))
+        cs_ = [api.plan_batch_counters(c) for c in (ctxs if K > 1 else [E.ctx])]
+        agg = {k: (sum if k in ("nodes_sent", "goal_grids", "expansions", "queries", "lanes") else max)(c[k] for c in cs_)
+               for k in cs_[0]}
+        # (t_heuristic_ms / t_search_ms are stamped per context: the largest of them is the rank's)
+        mine_c = dict(agg, contexts=len(cs_), t_heuristic_ms=float(max(s_.t_heuristic_ms for s_ in stt)),
+                      t_search_ms=float(max(s_.t_search_ms for s_ in stt)),
+                      cap_reached=int((r["status"] == A.PP_ERR_LIMIT).sum()))
+        E.ctx.set_host_threads(E.host_threads)
         if E.world > 1:
             allc = [None] * E.world
             E.dist.all_gather_object(allc, mine_c)
@@ -566,16 +589,18 @@ def main():
     ctx = api.Context(dev_index, stream.cuda_stream)
     # the planner's worker threads spin between rounds: several ranks on one node share its cores
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    host_threads = 15
     if local_world > 1:
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 16)
-        ctx.set_host_threads(max(1, min(15, cores // local_world - 1)))
+        host_threads = max(1, min(15, cores // local_world - 1))
+        ctx.set_host_threads(host_threads)
     conf = A.demo_config()
     if args.car == "compact":
         conf.car.center2front, conf.car.center2back, conf.car.width, conf.extend_bound = 3.0, 1.0, 1.8, 0.2
     if args.band > 0:
         assert ctx.lib.pp_ctx_set_relax_band(ctx.h, args.band) == 0
     E = SimpleNamespace(torch=torch, api=api, W=W, A=A, S=S, ctx=ctx, conf=conf, dev=dev, rank=rank, world=world,
-                        dist=dist)
+                        dist=dist, host_threads=host_threads)
     rehearsal = (f"{world} ranks on {ndev} GPU(s), reductions over {backend}: a rehearsal of the multi-rank path, "
                  "not a scaling measurement") if world > 1 and (backend != "nccl" or ndev < local_world_env) else None
 

@@ -233,8 +233,12 @@ __device__ __forceinline__ int pp_lattice_filter(double x, double y, float cf, f
   // the tile that starts at or before the window's low corner holds all of it: rows ytop & 15 ..
   // + 12 < 32, columns (ix0 & 15) .. + 12 < 32; the four block rows from yb are uint4 (yb & 15) >> 2 .. + 3
   unsigned key = 0;
+#ifdef PP_LAB_ONE_LINE  // timing ablation: every lane reads the same line (wrong flags, no gather cost)
+  const uint4* base = g.tiles + (size_t)((ytop & 15) >> 2);
+#else
   const uint4* base = g.tiles + (((size_t)(ix0 >> 4) * (size_t)g.nty + (size_t)(ytop >> 4)) * 8 +
                                  (size_t)((ytop & 15) >> 2));
+#endif
   if (ROWS == 8) {
     const uint4 l0 = base[0], l1 = base[1];
     key = pp_scan_rows4<0>(q, l0, key);

@@ -81,8 +81,9 @@ def parse():
     ap.add_argument("--contexts", type=int, default=0,
                     help="queries workload: contexts (stream + host threads each) per GPU that share a rank's "
                          "queries through pp_plan_batch_multi, so that the latency-bound rounds of one overlap the "
-                         "others' (default: 1 = plain pp_plan_batch; with --heavy 4, where the host side of a round is the bottleneck "
-                         "and four smaller batches keep their tables in cache better than one)")
+                         "others' (default 1: plain pp_plan_batch, which plans a batch of this size in four parts by itself)")
+    ap.add_argument("--batch-parts", type=int, default=0,
+                    help="queries workload: pp_ctx_set_batch_parts (0 = the library's choice, 1 = never split)")
     ap.add_argument("--weak", action="store_true",
                     help="queries workload: --queries is the count per rank (weak scaling) instead of the total")
     ap.add_argument("--heavy", action="store_true",
@@ -390,6 +391,7 @@ def wl_queries(args, E):
     occ = W.plan_map(args.map, dens)
     omap = api.ObstacleMap(E.ctx, raster=occ)
     E.ctx.set_max_expansions(max_exp)
+    E.ctx.set_batch_parts(args.batch_parts)
     # candidates whose start or goal pose collides are dropped (device check), then the
     # first --queries survivors are dealt round-robin to the ranks
     total = args.queries * (E.world if args.weak else 1)
@@ -417,7 +419,7 @@ def wl_queries(args, E):
                 "parallelism": f"query-sharded x{E.world}",
                 "deal": ("whole goal groups per rank" if args.deal == "goal" else "round-robin") if E.world > 1 else None})
     last = {}
-    K = args.contexts if args.contexts > 0 else (4 if args.heavy else 1)
+    K = args.contexts if args.contexts > 0 else 1
     wl.config["contexts_per_gpu"] = K
     if K > 1:
         base_threads = E.host_threads

@@ -131,6 +131,7 @@ def load_library(path=None):
         "pp_ctx_set_heuristic_workspace": (C.c_int32, [vp, C.c_uint64]),
         "pp_ctx_set_host_threads": (C.c_int32, [vp, C.c_uint32]),
         "pp_ctx_set_table_budget": (C.c_int32, [vp, C.c_uint64]),
+        "pp_ctx_set_batch_parts": (C.c_int32, [vp, C.c_uint32]),
         "pp_ctx_device_bytes": (C.c_uint64, [vp]),
         "pp_plan_batch_counters": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
         "pp_wavefront_stats": (C.c_int32, [vp, c_u64_p]),

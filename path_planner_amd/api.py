@@ -59,6 +59,10 @@ class Context:
         """Worker threads plan_batch may start beside the calling thread (default 15)."""
         _chk(self.lib.pp_ctx_set_host_threads(self.h, int(n)), "pp_ctx_set_host_threads")
 
+    def set_batch_parts(self, parts):
+        """Parts a large plan_batch runs in on this context (0 = automatic, 1 = never split)."""
+        _chk(self.lib.pp_ctx_set_batch_parts(self.h, int(parts)), "pp_ctx_set_batch_parts")
+
     def set_table_budget(self, nbytes):
         """Device memory plan_batch may take for its per-query tables of known cells (default 16 GiB,
         0 = no tables); the plans do not depend on it."""

@@ -54,6 +54,9 @@ extern "C" void pp_ctx_destroy(pp_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (pp_ctx* h : ctx->helpers) pp_ctx_destroy(h);
+  ctx->helpers.clear();
+  (void)hipSetDevice(ctx->device);
   if (ctx->slabs && ctx->slabs_orphan) ctx->slabs_orphan(ctx);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->wave_resume && ctx->wave_resume_free) ctx->wave_resume_free(ctx->wave_resume);
@@ -114,6 +117,12 @@ extern "C" int32_t pp_ctx_set_table_budget(pp_ctx* ctx, uint64_t bytes) {
   return PP_OK;
 }
 
+extern "C" int32_t pp_ctx_set_batch_parts(pp_ctx* ctx, uint32_t parts) {
+  if (!ctx || parts > 64) return PP_ERR_INVALID;
+  ctx->batch_parts = parts;
+  return PP_OK;
+}
+
 extern "C" int32_t pp_ctx_set_host_threads(pp_ctx* ctx, uint32_t n) {
   if (!ctx) return PP_ERR_INVALID;
   ctx->host_threads = std::min<uint32_t>(n, 255);
@@ -122,7 +131,9 @@ extern "C" int32_t pp_ctx_set_host_threads(pp_ctx* ctx, uint32_t n) {
 
 extern "C" uint64_t pp_ctx_device_bytes(const pp_ctx* ctx) {
   if (!ctx) return 0;
-  return (uint64_t)ctx->scratch_bytes + ctx->wave_bytes + ctx->ftab_bytes + ctx->plan_bytes + ctx->hmap_bytes;
+  uint64_t b = (uint64_t)ctx->scratch_bytes + ctx->wave_bytes + ctx->ftab_bytes + ctx->plan_bytes + ctx->hmap_bytes;
+  for (const pp_ctx* h : ctx->helpers) b += pp_ctx_device_bytes(h);
+  return b;
 }
 
 extern "C" int32_t pp_last_hip_error(pp_ctx* ctx) { return ctx ? ctx->last_hip_error : 0; }

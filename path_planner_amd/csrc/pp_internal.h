@@ -98,6 +98,10 @@ struct pp_ctx {
   void* plan_state = nullptr;
   void (*plan_state_free)(void*) = nullptr;
   uint64_t plan_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // last pp_plan_batch (pp_plan_batch_counters)
+  // a large pp_plan_batch runs as several parts, each on a helper context of this device (owned)
+  std::vector<pp_ctx*> helpers;
+  bool is_helper = false;
+  uint32_t batch_parts = 0;  // 0 = chosen from the batch size and host_threads (pp_ctx_set_batch_parts)
   // slab sessions created on this context and not yet destroyed (a list owned by pp_heuristic.hip);
   // pp_ctx_destroy releases their device memory and leaves the handles inert
   void* slabs = nullptr;

@@ -453,6 +453,43 @@ def test_batch_over_several_contexts_equals_one_context(ctx):
             o.close()
 
 
+def test_batch_planned_in_parts_equals_unsplit(ctx):
+    """From 2048 queries on pp_plan_batch plans a batch in up to four parts on streams of their own
+    (pp_ctx_set_batch_parts: 0 = that choice, 1 = never, n = always n).  Every query comes out the same
+    whichever part it is planned in, failing and capped queries included."""
+    occ = W.plan_map(1024, 0.012)
+    m = api.ObstacleMap(ctx, raster=occ)
+    cs, cg = W.plan_queries(7000, 1024, 11, min_dist=20.0, max_dist=120.0)
+    fs = api.collision_flags(ctx, m, CONF, cs[:, 0], cs[:, 1], cs[:, 2])
+    fg = api.collision_flags(ctx, m, CONF, cg[:, 0], cg[:, 1], cg[:, 2])
+    inside = (cs[:, 0] > 8) & (cs[:, 0] < 1015) & (cs[:, 1] > 8) & (cs[:, 1] < 1015)
+    keep = np.nonzero(inside & (fs == 0) & (fg == 0))[0][:2100]
+    assert len(keep) == 2100
+    starts, goals = cs[keep].copy(), cg[keep].copy()
+    starts[7] = goals[7]
+    keys = ("status", "len", "cost", "x", "y", "yaw", "dir", "closed")
+    ctx.set_max_expansions(120)
+    runs = []
+    try:
+        for parts in (1, 0, 3):
+            ctx.set_batch_parts(parts)
+            r = api.plan_batch(ctx, m, CONF, starts, goals, cap=1024, closed_cap=120)
+            runs.append({k: np.array(r[k], copy=True) for k in keys})
+            runs[-1]["exp"] = np.array([int(s.expansions) for s in r["stats"]])
+            runs[-1]["counters"] = api.plan_batch_counters(ctx)
+    finally:
+        ctx.set_batch_parts(0)
+        ctx.set_max_expansions(100000)
+    seen = set(int(v) for v in runs[0]["status"])
+    assert {A.PP_OK, A.PP_ERR_LIMIT, A.PP_ERR_DEGENERATE_RS} <= seen, seen
+    for r in runs[1:]:
+        for k in keys + ("exp",):
+            assert np.array_equal(runs[0][k], r[k], equal_nan=True), k
+    # the automatic choice split this batch (more lanes than one part has), and all of it was planned
+    assert runs[1]["counters"]["lanes"] > runs[0]["counters"]["lanes"]
+    assert all(r["counters"]["queries"] == len(starts) for r in runs)
+
+
 def test_host_thread_count_does_not_change_a_batch(ctx):
     """pp_ctx_set_host_threads only says how many threads apply a round's results."""
     ox, oy = W.demo_obstacles()

@@ -1619,9 +1619,19 @@ static int32_t plan_batch_dealt(pp_ctx* const* ctxs, const pp_map* const* maps, 
                                                      h.paths.data(), stats ? h.stats.data() : nullptr,
                                                      h.status.data());
   };
+  // a thread per share, the calling thread taking the first; a share whose thread cannot be started
+  // (no exception may cross the C boundary) is planned by the calling thread afterwards
   std::vector<std::thread> th;
-  for (uint32_t k = 1; k < n_ctx; ++k) th.emplace_back(run, k);
-  run(0);  // the calling thread takes the first share
+  std::vector<uint32_t> left;
+  for (uint32_t k = 1; k < n_ctx; ++k) {
+    try {
+      th.emplace_back(run, k);
+    } catch (...) {
+      left.push_back(k);
+    }
+  }
+  run(0);
+  for (uint32_t k : left) run(k);
   for (auto& t : th) t.join();
   int32_t ret = PP_OK;
   for (uint32_t k = 0; k < n_ctx; ++k) {

@@ -391,7 +391,7 @@ def wl_queries(args, E):
     occ = W.plan_map(args.map, dens)
     omap = api.ObstacleMap(E.ctx, raster=occ)
     E.ctx.set_max_expansions(max_exp)
-    E.ctx.set_batch_parts(args.batch_parts)
+    E.ctx.set_batch_parts(args.batch_parts or int(os.environ.get("PP_BENCH_BATCH_PARTS", "0")))
     # candidates whose start or goal pose collides are dropped (device check), then the
     # first --queries survivors are dealt round-robin to the ranks
     total = args.queries * (E.world if args.weak else 1)
@@ -664,7 +664,7 @@ def main():
         torch.cuda.empty_cache()
         out["extra"] = {}
         legs = [("rs", {"workload": "rs"}, 10, 2), ("wavefront", {"workload": "wavefront"}, 2, 1),
-                ("queries", {"workload": "queries"}, 2, 1), ("queries_heavy", {"workload": "queries", "heavy": True}, 2, 1)]
+                ("queries", {"workload": "queries"}, 6, 2), ("queries_heavy", {"workload": "queries", "heavy": True}, 2, 1)]
         for name, over, steps, warmup in legs:
             a = argparse.Namespace(**{**vars(parse_defaults()), **over, "no_cpu_baseline": args.no_cpu_baseline})
             try:
@@ -706,8 +706,8 @@ def main():
         dog = threading.Timer(args.extra_timeout, give_up)
         dog.daemon = True
         dog.start()
-        for name, over, steps, warmup in [("queries", {"workload": "queries"}, 2, 1),
-                                          ("queries_weak", {"workload": "queries", "weak": True}, 2, 1),
+        for name, over, steps, warmup in [("queries", {"workload": "queries"}, 6, 2),
+                                          ("queries_weak", {"workload": "queries", "weak": True}, 6, 2),
                                           ("wavefront", {"workload": "wavefront"}, 2, 1)]:
             in_flight[0] = name
             # sizes as given on the command line (the BASELINE sizes unless a rehearsal shrinks them)

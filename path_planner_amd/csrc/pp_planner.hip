@@ -1572,7 +1572,10 @@ static int32_t plan_batch_dealt(pp_ctx* const* ctxs, const pp_map* const* maps, 
                                 const double* goals, pp_path* out, pp_plan_stats* stats, int32_t* status,
                                 bool core) {
   if (!(conf->xy_reso > 0.0)) return PP_ERR_INVALID;
-  // order by goal cell, ties by position (queries of one goal keep their order)
+  // Order by goal cell, ties by position (queries of one goal keep their order), the goal groups
+  // taken in turn: group r of the sorted cells goes to the front of share r mod n_ctx.  Neighbouring
+  // goals tend to be equally hard (the same cluttered corner of the map), and a contiguous run of
+  // them would make one share the slowest.
   std::vector<uint64_t> order(nq);
   std::vector<std::pair<uint64_t, uint64_t>> cell(nq);
   for (uint64_t i = 0; i < nq; ++i) {
@@ -1581,6 +1584,16 @@ static int32_t plan_batch_dealt(pp_ctx* const* ctxs, const pp_map* const* maps, 
                pp_sat_usize(std::round(goals[3 * i + 1] / conf->xy_reso))};
   }
   std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return cell[a] < cell[b]; });
+  {
+    std::vector<uint64_t> rank(nq);  // rank of a query's goal cell among the distinct cells
+    uint64_t r = 0;
+    for (uint64_t k = 0; k < nq; ++k) {
+      if (k && cell[order[k]] != cell[order[k - 1]]) ++r;
+      rank[order[k]] = r;
+    }
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint64_t a, uint64_t b) { return rank[a] % n_ctx < rank[b] % n_ctx; });
+  }
   struct Share {
     std::vector<uint64_t> ids;
     std::vector<double> s, g;

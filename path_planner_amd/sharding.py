@@ -30,23 +30,26 @@ def query_shard(ids, rank, world):
     return ids[rank::world]
 
 
-def goal_order(goal_keys):
-    """Positions of a query list ordered by goal (stable: queries of one goal keep their order).
+def goal_order(goal_keys, world=1):
+    """Positions of a query list ordered by goal (stable: queries of one goal keep their order), the
+    goal groups taken in turn: group r of the sorted goals comes in the r mod world-th stretch of the
+    order, so that a run of neighbouring (often equally hard) goals is spread over the ranks.
     goal_keys: one hashable-by-value row per query (e.g. the goal's heuristic-grid cell)."""
     keys = np.asarray(goal_keys)
     keys = keys.reshape(len(keys), -1)
     _, inv = np.unique(keys, axis=0, return_inverse=True)
-    return np.argsort(np.asarray(inv).reshape(-1), kind="stable")
+    inv = np.asarray(inv).reshape(-1)
+    return np.lexsort((np.arange(len(inv)), inv, inv % world))
 
 
 def query_shard_by_goal(goal_keys, rank, world):
     """Positions (into the undealt list) of this rank's share when the list is dealt by goal: the
-    queries are ordered by goal and cut into `world` runs of equal length (+-1), so a rank holds
-    whole goal groups except for at most one group shared with each neighbour.  The planner
+    queries are ordered by goal (goal_order) and cut into `world` runs of equal length (+-1), so a
+    rank holds whole goal groups except for at most one group shared with each neighbour.  The planner
     relaxes one heuristic grid per distinct goal cell of its batch: dealt this way a rank relaxes
     about n_goals / world + 1 grids instead of all of them, at equal query counts.  (Queries of
     different goals can differ in length, so the shares are equal in queries, not in work.)"""
-    order = goal_order(goal_keys)
+    order = goal_order(goal_keys, world)
     n = len(order)
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world
     return np.sort(order[lo:hi])

@@ -654,6 +654,8 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
   constexpr size_t kRoundOutHostMin = PP_ROUND_OUT_HOST_MIN;  // nodes; from this on results go straight to it
   // a large batch runs as two lanes (below), each with its own half of the staging buffers
   constexpr size_t kTwoLanesMin = 1024, kLaneMergeBelow = 256;
+  // a lane's staging area holds Bl nodes (below): a round with look-ahead sends up to kSpecItems
+  static_assert(kSpecItems + kSpecDepth <= kTwoLanesMin / 2, "the look-ahead must fit a lane's staging area");
   const bool two_lanes = nq >= kTwoLanesMin;
   const size_t Bl = two_lanes ? (nq + 1) / 2 : std::max<size_t>(nq, kSpecItems + kSpecDepth);  // items per lane
   const size_t B = two_lanes ? 2 * Bl : Bl;

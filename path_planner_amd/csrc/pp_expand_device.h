@@ -140,8 +140,8 @@ __device__ __forceinline__ void pp_expand_item(uint64_t t, uint32_t n_prim, cons
   // bit3: the index test passed, i.e. the primitive's poses were handed to is_collision
   unsigned v = (valid ? 1u : 0u) | (amb ? 2u : 0u) | ((fl & PP_F_NONFINITE) ? 4u : 0u) |
                (in_bounds ? 8u : 0u) | (known ? 32u : 0u);
-  if (out.fcost) {
-    double fc = 0.0;
+  double fc = 0.0;
+  if (out.fcost || out.rec) {
     if (valid) {
       // is_index_ok guarantees minx < xind < maxx, so the lookup is inside the grid
       uint64_t hx = xind - prm.minx, hy = yind - prm.miny;
@@ -155,9 +155,19 @@ __device__ __forceinline__ void pp_expand_item(uint64_t t, uint32_t n_prim, cons
         fc = __longlong_as_double(0x7FF8000000000000ll);
       }
     }
-    if (!(out.sparse && !valid)) out.fcost[t] = fc;
+    if (out.fcost && !(out.sparse && !valid)) out.fcost[t] = fc;
   }
   out.valid[t] = (uint8_t)v;
+  if (out.rec) {  // one 64-byte line per valid primitive instead of eight scattered words
+    if (valid) {
+      ulonglong2* r = (ulonglong2*)(out.rec + 8 * t);
+      r[0] = make_ulonglong2(xind, yind);
+      r[1] = make_ulonglong2((unsigned long long)yawind, (unsigned long long)__double_as_longlong(cost));
+      r[2] = make_ulonglong2((unsigned long long)__double_as_longlong(x), (unsigned long long)__double_as_longlong(y));
+      r[3] = make_ulonglong2((unsigned long long)__double_as_longlong(yaw), (unsigned long long)__double_as_longlong(fc));
+    }
+    return;
+  }
   if (out.sparse && !valid) return;  // the caller reads the other arrays only where bit 0 is set
   out.xind[t] = valid ? xind : 0;
   out.yind[t] = valid ? yind : 0;

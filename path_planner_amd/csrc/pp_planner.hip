@@ -231,20 +231,26 @@ class OpenHeap {
 struct Expansion {
   PpShotOut shot;
   std::vector<uint8_t> valid;   // P
-  std::vector<uint64_t> words;  // 8 x P: xind, yind, yawind, cost, end x, end y, end yaw, f (as bits)
+  std::unique_ptr<uint64_t[]> words;  // P records of 8 (PpExpandDev::rec), those of the valid primitives filled in
 };
 // The same data in place, in the round's staging buffer or in a cache entry.
 struct ExpansionView {
   const PpShotOut* shot;
   const uint8_t* valid;
-  const uint64_t* xind;
-  const uint64_t* yind;
-  const int64_t* yawind;
-  const double* cost;
-  const double* ex;
-  const double* ey;
-  const double* eyaw;
-  const double* f;
+  const uint64_t* rec;  // primitive i's record at rec + 8 i, meaningful where valid[i] has bit 0
+  uint64_t xind(uint32_t i) const { return rec[8 * i]; }
+  uint64_t yind(uint32_t i) const { return rec[8 * i + 1]; }
+  int64_t yawind(uint32_t i) const { return (int64_t)rec[8 * i + 2]; }
+  double cost(uint32_t i) const { return f64(rec[8 * i + 3]); }
+  double ex(uint32_t i) const { return f64(rec[8 * i + 4]); }
+  double ey(uint32_t i) const { return f64(rec[8 * i + 5]); }
+  double eyaw(uint32_t i) const { return f64(rec[8 * i + 6]); }
+  double f(uint32_t i) const { return f64(rec[8 * i + 7]); }
+  static double f64(uint64_t b) {
+    double v;
+    std::memcpy(&v, &b, 8);
+    return v;
+  }
 };
 
 struct Query {
@@ -255,7 +261,6 @@ struct Query {
   OpenHeap heap;
   std::unordered_map<int32_t, Expansion> cache;  // expansions fetched ahead of their node's turn
   std::vector<int32_t> want;                     // nodes to expand in this round, want[0] = curr
-  size_t item0 = 0;                              // this query's first item in the round's batch
   int32_t status = PP_OK;
   bool live = false;
   int32_t ftab = -1;               // the query's table of known cells on the device (pp_expand.h), -1 = none
@@ -275,7 +280,6 @@ struct Query {
     heap.clear();
     cache.clear();
     want.clear();
-    item0 = 0;
     status = PP_OK;
     live = false;
     ftab = -1;
@@ -653,7 +657,11 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
 #endif
   constexpr size_t kRoundOutHostMin = PP_ROUND_OUT_HOST_MIN;  // nodes; from this on results go straight to it
   // a large batch runs as two lanes (below), each with its own half of the staging buffers
+#ifndef PP_LANE_MERGE_WAIT
+#define PP_LANE_MERGE_WAIT 0.3
+#endif
   constexpr size_t kTwoLanesMin = 1024, kLaneMergeBelow = 256;
+  constexpr double kLaneMergeWaitShare = PP_LANE_MERGE_WAIT;
   // a lane's staging area holds Bl nodes (below): a round with look-ahead sends up to kSpecItems
   static_assert(kSpecItems + kSpecDepth <= kTwoLanesMin / 2, "the look-ahead must fit a lane's staging area");
   const bool two_lanes = nq >= kTwoLanesMin;
@@ -670,7 +678,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
   // device buffer and one pinned mirror, laid out per round; the motion table and the
   // Reeds-Shepp work arrays sit behind them
   const size_t io_lane = al256(6 * Bl * 8) + 3 * al256(Bl * 8) + 2 * al256(Bl * 4) + al256(Bl * sizeof(PpShotOut)) +
-                         al256(items) + 8 * al256(items * 8);
+                         al256(items) + al256(items * 64);
   const size_t io_bytes = (two_lanes ? 2 : 1) * io_lane;
   // pinned only, behind the mirror: per lane, the news of a round for the tables of known cells
   const size_t upd_cap = Bl * (NP + 2);
@@ -757,6 +765,11 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     };
     if (so.flags & 2u) guard_band();
     if (so.flags & (4u | 8u | 16u)) {
+#ifdef PP_LAB_CHECK
+      fprintf(stderr, "[check] ctx %p query ends on shot flags %x n_paths %d idx %d gen %d cost %g handed %u pad %x at expansion %llu node %d\n",
+              (void*)ctx, so.flags, so.n_paths, so.path_idx, so.gen, so.cost, so.poses_handed, so.pad_,
+              (unsigned long long)q.st.expansions, q.curr);
+#endif
       q.status = (so.flags & 4u) ? PP_ERR_DEGENERATE_RS : (so.flags & 8u) ? PP_ERR_NAN_COST : PP_ERR_NONFINITE;
       q.live = false;
       return;
@@ -775,10 +788,12 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     // keys of the valid children first, with their table lines requested, then the lookups
     uint64_t ckey[256];
     const bool keyed = NP <= 256;
+    for (uint32_t i = 0; i < NP; ++i)
+      if (v.valid[i] & 1u) __builtin_prefetch(v.rec + 8 * i);
     if (keyed)
       for (uint32_t i = 0; i < NP; ++i)
         if (v.valid[i] & 1u) {
-          ckey[i] = calc_index(v.xind[i], v.yind[i], v.yawind[i], P);
+          ckey[i] = calc_index(v.xind(i), v.yind(i), v.yawind(i), P);
           q.tab.prefetch(ckey[i]);
         }
     for (uint32_t i = 0; i < NP; ++i) {
@@ -792,24 +807,24 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
         return;
       }
       if (!(vf & 1u)) continue;
-      const uint64_t key = keyed ? ckey[i] : calc_index(v.xind[i], v.yind[i], v.yawind[i], P);
-      const double cost = v.cost[i];
+      const uint64_t key = keyed ? ckey[i] : calc_index(v.xind(i), v.yind(i), v.yawind(i), P);
+      const double cost = v.cost(i);
       NodeTable::Slot* sl = q.tab.find(key);
       if (sl && (sl->state() == NodeTable::kClosed || !(sl->cost > cost))) continue;
-      const double f = v.f[i];
+      const double f = v.f(i);
       if (f != f) {  // NotNan::new(..).unwrap()
         q.status = PP_ERR_NAN_COST;
         q.live = false;
         return;
       }
       SNode n;
-      n.xind = v.xind[i];
-      n.yind = v.yind[i];
-      n.yawind = v.yawind[i];
+      n.xind = v.xind(i);
+      n.yind = v.yind(i);
+      n.yawind = v.yawind(i);
       n.direction = mot[NP + i] > 0.0 ? 1 : -1;
-      n.x = v.ex[i];
-      n.y = v.ey[i];
-      n.yaw = v.eyaw[i];
+      n.x = v.ex(i);
+      n.y = v.ey(i);
+      n.yaw = v.eyaw(i);
       n.steer = mot[i];
       n.cost = cost;
       n.pind = (int64_t)q.curr_key;
@@ -827,12 +842,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
       if (q.ftab >= 0) q.upd.push_back(PpFtabUpd{key, f64_bits(cost), q.ftab, 0});
     }
   };
-  auto view_of = [&](const Expansion& e) {
-    const uint64_t* w = e.words.data();
-    return ExpansionView{&e.shot, e.valid.data(), w, w + NP, (const int64_t*)(w + 2 * NP),
-                         (const double*)(w + 3 * NP), (const double*)(w + 4 * NP), (const double*)(w + 5 * NP),
-                         (const double*)(w + 6 * NP), (const double*)(w + 7 * NP)};
-  };
+  auto view_of = [&](const Expansion& e) { return ExpansionView{&e.shot, e.valid.data(), e.words.get()}; };
   // Closes nodes (hybrid_astar.rs:157-161) for as long as their expansions are already at hand;
   // returns with q.curr = the node the device has to expand next, or with the query finished.
   auto advance = [&](Query& q) {
@@ -910,14 +920,24 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
   // launches queue up behind the other lane's and its event says when its own results are in.
   struct Lane {
     std::vector<uint32_t> ids;  // live queries
-    std::vector<Emit> emit;     // ids[k]'s next node
+    // What the device needs of the nodes ids[k] wants expanded: `stride` records per query while
+    // the queries write them (emit[k * stride] = the node to close next, behind it emit_n[k] - 1
+    // nodes near the top of its open list), packed by launch() into one record per item, query k's
+    // first at item0[k].
+    std::vector<Emit> emit;
+    std::vector<uint8_t> emit_n;
+    std::vector<uint32_t> item0;
+    size_t stride = 1;
     size_t io_base = 0;         // the lane's part of the staging buffers (pinned and device), bytes
     size_t item_base = 0;       // the lane's part of the Reeds-Shepp work arrays, items
     hipEvent_t done = nullptr;
     bool in_flight = false;
     int pc = 0;
     size_t nl = 0, ni = 0, depth = 1;
-    size_t r_shot = 0, r_valid = 0, r_arr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t r_shot = 0, r_valid = 0, r_rec = 0;
+#ifdef PP_LAB_CHECK
+    size_t r_q = 0;
+#endif
     // news for the tables of known cells, written by the workers as they apply a round
     PpFtabUpd* upd = nullptr;
     std::atomic<uint32_t> upd_n{0}, upd_fail{UINT32_MAX};  // records reserved; lowest reservation that did not fit
@@ -956,21 +976,29 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     }
     q.want.clear();
     q.want.push_back(q.curr);
-    Emit& e = ln.emit[k];
-    e.alive = q.live;
+    Emit* const e0 = &ln.emit[k * ln.stride];
+    e0->alive = q.live;
+    ln.emit_n[k] = 1;
     if (!q.live) return;
-    const SNode& n = q.nodes[q.curr];
-    e.x = n.x;
-    e.y = n.y;
-    e.yaw = n.yaw;
-    e.gx = q.goal[0];
-    e.gy = q.goal[1];
-    e.gyaw = q.goal[2];
-    e.dir = n.direction;
-    e.steer = n.steer;
-    e.cost = n.cost;
-    e.hid = q.hmap_slot;
-    e.fid = q.ftab;
+    // the look-ahead is chosen here too, while the query's heap and tables are in this thread's cache
+    if (ln.stride > 1) speculate(q, ln.stride);
+    ln.emit_n[k] = (uint8_t)q.want.size();
+    for (size_t j = 0; j < q.want.size(); ++j) {
+      const SNode& n = q.nodes[q.want[j]];
+      Emit& e = e0[j];
+      e.x = n.x;
+      e.y = n.y;
+      e.yaw = n.yaw;
+      e.gx = q.goal[0];
+      e.gy = q.goal[1];
+      e.gyaw = q.goal[2];
+      e.dir = n.direction;
+      e.steer = n.steer;
+      e.cost = n.cost;
+      e.hid = q.hmap_slot;
+      e.fid = q.ftab;
+      e.alive = 1;
+    }
   };
 
   // Tables of known cells (pp_expand.h).  A search that is still running after kFtabStartRound
@@ -978,8 +1006,14 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
   // kept up to date round by round; from then on the device drops the rollouts the search would
   // drop anyway, which is most of them (on the search-heavy benchmark 82 % of the valid ones), and
   // the host never looks at them.  Short searches -- most of a typical batch -- never pay for it.
-  constexpr uint32_t kFtabStartRound = 64;
-  constexpr size_t kFtabMinLive = 64;
+#ifndef PP_FTAB_START
+#define PP_FTAB_START 64
+#endif
+  constexpr uint32_t kFtabStartRound = PP_FTAB_START;
+#ifndef PP_FTAB_MIN_LIVE
+#define PP_FTAB_MIN_LIVE 4
+#endif
+  constexpr size_t kFtabMinLive = PP_FTAB_MIN_LIVE;
   const size_t kFtabBudget = ctx->ftab_budget;  // bytes of device memory for all tables (pp_ctx_set_table_budget)
   // the cost bit patterns order like the costs only if no cost term can be negative
   bool ftab_off = !(plan.prm.backward_cost >= 0.0 && plan.prm.gear_cost >= 0.0 &&
@@ -1047,7 +1081,8 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
       Query& q = Q[ln.ids[k]];
       if (q.ftab >= 0 || ftab_next >= ftab_tables) continue;
       q.ftab = (int32_t)ftab_next++;
-      ln.emit[k].fid = q.ftab;
+      for (size_t it = ln.item0[k], end = k + 1 < ln.ids.size() ? ln.item0[k + 1] : ln.ni; it < end; ++it)
+        ln.emit[it].fid = q.ftab;
       fresh.push_back(ln.ids[k]);
       base.push_back(total);
       total += q.tab.size();
@@ -1092,17 +1127,23 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
   // number of items, so each direction is one copy of exactly what is used.
   auto launch = [&](Lane& ln) -> int32_t {
     const double p1 = prof ? now_ms() : 0.0;
-    size_t nl = 0;
+    size_t nl = 0, ni = 0;  // one node per live query, plus what the queries chose to send along
+    ln.item0.resize(ln.ids.size());
     for (size_t k = 0; k < ln.ids.size(); ++k)
-      if (ln.emit[k].alive) {
+      if (ln.emit[k * ln.stride].alive) {
         ln.ids[nl] = ln.ids[k];
-        ln.emit[nl] = ln.emit[k];
+        ln.item0[nl] = (uint32_t)ni;
+        for (size_t j = 0, n = ln.emit_n[k]; j < n; ++j) ln.emit[ni++] = ln.emit[k * ln.stride + j];  // ni <= k * stride
         ++nl;
       }
     ln.ids.resize(nl);
-    ln.emit.resize(nl);
     ln.nl = nl;
-    if (nl == 0) return PP_OK;
+    ln.ni = ni;
+    if (nl == 0) {  // the lane is done (a merge may still hand it the other lane's queries)
+      ln.emit.clear();
+      ln.emit_n.clear();
+      return PP_OK;
+    }
     ++ln.rounds;
     // a round of few nodes is latency, not host work: it runs without the tables (what they miss
     // of its news only makes them rule out less)
@@ -1116,19 +1157,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     if (!(tables && ftab_slots != 0)) n_upd = 0;
     eo.ftab = tables && ftab_slots != 0 ? (const unsigned long long*)ctx->ftab_buf : nullptr;
     ln.pc = nl < 64 ? 1 : 0;
-    const size_t depth = std::min<size_t>(kSpecDepth, std::max<size_t>(1, kSpecItems / nl));
-    size_t ni = nl;  // one node per query (item = position in the live list) ...
-    if (depth > 1) {  // ... unless few queries are left and each also sends nodes it may close soon
-      pool.run(nl, [&](size_t k) { speculate(Q[ln.ids[k]], depth); }, 1, 2);
-      ni = 0;
-      for (uint32_t id : ln.ids) {
-        Query& q = Q[id];
-        q.item0 = ni;
-        ni += q.want.size();
-      }
-    }
-    ln.depth = depth;
-    ln.ni = ni;
+    ln.depth = ln.stride;
     size_t ro = ln.io_base;
     auto rtake = [&](size_t bytes) {
       size_t o = ro;
@@ -1141,7 +1170,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     const size_t itn = ni * NP;
     ln.r_shot = rtake(ni * sizeof(PpShotOut));
     ln.r_valid = rtake(itn);
-    for (int a = 0; a < 8; ++a) ln.r_arr[a] = rtake(itn * 8);  // xind, yind, yawind, cost, end x, end y, end yaw, f
+    ln.r_rec = rtake(itn * 64);  // one 64-byte record per primitive (PpExpandDev::rec)
     const size_t r_out = ro - r_in;
     double* hq = (double*)(h + r_q);
     int64_t* hdir = (int64_t*)(h + r_dir);
@@ -1149,8 +1178,8 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     double* hcost = (double*)(h + r_cost);
     int32_t* hhid = (int32_t*)(h + r_hid);
     int32_t* hfid = (int32_t*)(h + r_fid);
-    if (depth == 1) {
-      pool.run(nl, [&](size_t k) {  // item = position in the live list, straight from the records
+    {
+      pool.run(ni, [&](size_t k) {  // straight from the records
         const Emit& e = ln.emit[k];
         hq[0 * ni + k] = e.x;
         hq[1 * ni + k] = e.y;
@@ -1163,27 +1192,18 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
         hcost[k] = e.cost;
         hhid[k] = e.hid;
         hfid[k] = e.fid;
-      }, 64);
-    } else {
-      pool.run(nl, [&](size_t li) {  // every query fills its own slots
-        Query& q = Q[ln.ids[li]];
-        for (size_t j = 0; j < q.want.size(); ++j) {
-          const SNode& n = q.nodes[q.want[j]];
-          const size_t k = q.item0 + j;
-          hq[0 * ni + k] = n.x;
-          hq[1 * ni + k] = n.y;
-          hq[2 * ni + k] = n.yaw;
-          hq[3 * ni + k] = q.goal[0];
-          hq[4 * ni + k] = q.goal[1];
-          hq[5 * ni + k] = q.goal[2];
-          hdir[k] = n.direction;
-          hsteer[k] = n.steer;
-          hcost[k] = n.cost;
-          hhid[k] = q.hmap_slot;
-          hfid[k] = q.ftab;
-        }
-      }, 1, 2);
+      }, 64, 512);
     }
+    // The next round's records: while few queries are left each also sends nodes it may close soon
+    // (kSpecItems nodes in all, by this round's count of live queries -- the next one's is not higher).
+    ln.stride = std::min<size_t>(kSpecDepth, std::max<size_t>(1, kSpecItems / nl));
+    ln.emit.resize(nl * ln.stride);
+    ln.emit_n.resize(nl);
+#ifdef PP_LAB_CHECK
+    ln.r_q = r_q;
+    std::memset(h + ln.r_shot, 0xEE, ni * sizeof(PpShotOut));
+    std::memset(h + ln.r_valid, 0xEE, itn);
+#endif
     const double p2 = prof ? now_ms() : 0.0;
     ++c_rounds;
     if (nl < 64) ++c_small;
@@ -1208,14 +1228,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     char* const od = out_host ? h : dd;
     eo.sparse = out_host ? 1 : 0;
     eo.valid = (uint8_t*)(od + ln.r_valid);
-    eo.xind = (uint64_t*)(od + ln.r_arr[0]);
-    eo.yind = (uint64_t*)(od + ln.r_arr[1]);
-    eo.yawind = (int64_t*)(od + ln.r_arr[2]);
-    eo.cost = (double*)(od + ln.r_arr[3]);
-    eo.end_x = (double*)(od + ln.r_arr[4]);
-    eo.end_y = (double*)(od + ln.r_arr[5]);
-    eo.end_yaw = (double*)(od + ln.r_arr[6]);
-    eo.fcost = (double*)(od + ln.r_arr[7]);
+    eo.rec = (uint64_t*)(od + ln.r_rec);
     eo.hmap_id = (const int32_t*)(dd + r_hid);
     eo.ftab_id = (const int32_t*)(dd + r_fid);
     const double* dq = (const double*)(dd + r_q);
@@ -1240,23 +1253,42 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     return PP_OK;
   };
 
+  double waited = 0.0;  // ms the host waited for results since the loop below last looked
   // (3) wait for the lane's results; the closed node is applied straight from the staging buffer,
   // the nodes fetched ahead of their turn go into the query's cache
   auto collect = [&](Lane& ln) -> int32_t {
     if (!ln.in_flight) return PP_OK;
-    const double p2 = prof ? now_ms() : 0.0;
+    const double p2 = now_ms();
     PP_HIP(ctx, hipEventSynchronize(ln.done));
     ln.in_flight = false;
-    const double p3 = prof ? now_ms() : 0.0;
+    const double p3 = now_ms();
+    waited += p3 - p2;
     if (prof) p_dev[ln.pc] += p3 - p2;
     const PpShotOut* shot = (const PpShotOut*)(h + ln.r_shot);
     const uint8_t* v_valid = (const uint8_t*)(h + ln.r_valid);
-    const char* v_arr[8];
-    for (int a = 0; a < 8; ++a) v_arr[a] = h + ln.r_arr[a];
+    const uint64_t* v_rec = (const uint64_t*)(h + ln.r_rec);
+#ifdef PP_LAB_CHECK
+    {
+      size_t bad_shot = 0, bad_valid = 0, first = ~(size_t)0;
+      for (size_t it = 0; it < ln.ni; ++it) {
+        if (shot[it].pad_ == 0xEEEEEEEEu || shot[it].flags > 31u || shot[it].n_paths < 0 || shot[it].n_paths > 46) {
+          ++bad_shot;
+          if (first == ~(size_t)0) first = it;
+        }
+        for (size_t i = 0; i < NP; ++i)
+          if (v_valid[it * NP + i] > 63u) ++bad_valid;
+      }
+      if (bad_shot || bad_valid)
+        fprintf(stderr, "[check] ctx %p lane %d round %u: ni %zu nl %zu stride %zu: %zu bad shots (first item %zu: flags %x n_paths %d pad %x), %zu bad valid bytes\n",
+                (void*)ctx, (int)(&ln - lanes), ln.rounds, ln.ni, ln.nl, ln.depth, bad_shot, first,
+                first != ~(size_t)0 ? shot[first].flags : 0u, first != ~(size_t)0 ? shot[first].n_paths : 0,
+                first != ~(size_t)0 ? shot[first].pad_ : 0u, bad_valid);
+    }
+#endif
     const size_t depth = ln.depth;
     pool.run(ln.nl, [&](size_t k) {
       Query& q = Q[ln.ids[k]];
-      const size_t first = depth == 1 ? k : q.item0;
+      const size_t first = ln.item0[k];
       // entries of nodes that were replaced in the open list are never asked for again: a long
       // search drops the lot now and then (whatever is still wanted is simply fetched again)
       if (q.cache.size() > kCacheMax) q.cache.clear();
@@ -1265,23 +1297,31 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
         Expansion& e = q.cache[q.want[j]];
         e.shot = shot[it];
         e.valid.assign(v_valid + it * NP, v_valid + (it + 1) * NP);
-        e.words.resize(8 * (size_t)NP);
-        for (int a = 0; a < 8; ++a) std::memcpy(e.words.data() + (size_t)a * NP, v_arr[a] + it * NP * 8, (size_t)NP * 8);
+        if (!e.words) e.words.reset(new uint64_t[8 * (size_t)NP]);
+        for (uint32_t i = 0; i < NP; ++i)
+          if (e.valid[i] & 1u) std::memcpy(e.words.get() + 8 * (size_t)i, v_rec + 8 * (it * NP + i), 64);
       }
       // the next query's results (written by the device: in no cache) and the query itself
       if (depth == 1 && k + 1 < ln.nl) {
         const size_t nb = (k + 1) * NP;
         __builtin_prefetch(&shot[k + 1]);
         for (size_t o = 0; o < NP; o += 64) __builtin_prefetch(v_valid + nb + o);
-        for (int a = 0; a < 8; ++a)
-          for (size_t o = 0; o < (size_t)NP * 8; o += 64) __builtin_prefetch(v_arr[a] + nb * 8 + o);
         const char* qn = (const char*)&Q[ln.ids[k + 1]];
         for (size_t o = 0; o < sizeof(Query); o += 64) __builtin_prefetch(qn + o);
       }
       const size_t it = first, b = it * NP;
-      const ExpansionView v{&shot[it], v_valid + b, (const uint64_t*)v_arr[0] + b, (const uint64_t*)v_arr[1] + b,
-                            (const int64_t*)v_arr[2] + b, (const double*)v_arr[3] + b, (const double*)v_arr[4] + b,
-                            (const double*)v_arr[5] + b, (const double*)v_arr[6] + b, (const double*)v_arr[7] + b};
+#ifdef PP_LAB_CHECK
+      for (size_t j = 0; j < q.want.size(); ++j)
+        if (shot[first + j].flags & 4u) {
+          const double* hq = (const double*)(h + ln.r_q);
+          const SNode& n = q.nodes[q.want[j]];
+          const size_t i2 = first + j;
+          fprintf(stderr, "[check] lane %d round %u item %zu (+%zu of %zu) ni %zu: staged start %.17g %.17g %.17g goal %.17g %.17g %.17g | node %.17g %.17g %.17g goal %.17g %.17g %.17g\n",
+                  (int)(&ln - lanes), ln.rounds, i2, j, q.want.size(), ln.ni, hq[i2], hq[ln.ni + i2], hq[2 * ln.ni + i2],
+                  hq[3 * ln.ni + i2], hq[4 * ln.ni + i2], hq[5 * ln.ni + i2], n.x, n.y, n.yaw, q.goal[0], q.goal[1], q.goal[2]);
+        }
+#endif
+      const ExpansionView v{&shot[it], v_valid + b, v_rec + 8 * b};
       if (beyond_limit(v)) {
         need_grids.store(true, std::memory_order_relaxed);  // q.curr stays: the node goes to the device again
       } else {
@@ -1316,6 +1356,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     Lane& ln = lanes[l];
     const double p0 = prof ? now_ms() : 0.0;
     ln.emit.resize(ln.ids.size());
+    ln.emit_n.resize(ln.ids.size());
     pool.run(ln.ids.size(), [&](size_t k) { advance_emit(ln, k); });
     if (prof) p_adv[ln.ids.size() < 64 ? 1 : 0] += now_ms() - p0;
   }
@@ -1324,24 +1365,52 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     if (st != PP_OK) return drain(st);
   }
   bool merged = nlanes == 1;
+  // Two lanes pay off while the host is the slower side: one lane's results are applied and its
+  // next nodes chosen while the other's kernels run.  With few queries left and little to apply a
+  // round is the device's latency, and the host mostly waits for it: then one lane is better (one
+  // launch per round instead of two that take turns on the stream).  wait_sum / turn_sum is the
+  // part of the recent turns of the loop below the host spent waiting for a lane's results.
+  double wait_sum = 0.0, turn_sum = 0.0, turn_begin = now_ms();
+  // test hook: PP_PLAN_MERGE_TURN=n merges at turn n of the loop whatever the lanes hold (the
+  // closing orders must not depend on where the merge happens)
+  const char* const merge_env = getenv("PP_PLAN_MERGE_TURN");
+  const long merge_turn = merge_env ? atol(merge_env) : -1;
+  long turn = 0;
   while (lanes[0].in_flight || lanes[1].in_flight) {
+    ++turn;
+    {
+      const double t = now_ms();
+      wait_sum = wait_sum * (15.0 / 16.0) + waited;
+      turn_sum = turn_sum * (15.0 / 16.0) + (t - turn_begin);
+      waited = 0.0;
+      turn_begin = t;
+    }
     for (size_t l = 0; l < nlanes; ++l) {
       Lane& ln = lanes[l];
       st = collect(ln);
       if (st != PP_OK) return drain(st);
-      // few queries left: one lane again (a round of a handful of nodes is latency, not work, and
-      // the look-ahead shares its budget over one lane's queries)
-      if (!merged && l == 0 && lanes[0].ids.size() + lanes[1].ids.size() < kLaneMergeBelow) {
+      const bool few = lanes[0].ids.size() + lanes[1].ids.size() < kLaneMergeBelow;
+      if (!merged && l == 0 &&
+          (merge_turn >= 0 ? turn == merge_turn : few && wait_sum > kLaneMergeWaitShare * turn_sum)) {
         st = collect(lanes[1]);
         if (st != PP_OK) return drain(st);
         Lane& o = lanes[1];
+        if (o.stride > ln.stride) {  // records of one stride: spread lane 0's out, back to front
+          ln.emit.resize(ln.ids.size() * o.stride);
+          for (size_t k = ln.ids.size(); k-- > 0;)
+            for (size_t j = ln.emit_n[k]; j-- > 0;) ln.emit[k * o.stride + j] = ln.emit[k * ln.stride + j];
+          ln.stride = o.stride;
+        }
         for (size_t k = 0; k < o.ids.size(); ++k)
-          if (o.emit[k].alive) {
+          if (o.emit[k * o.stride].alive) {
             ln.ids.push_back(o.ids[k]);
-            ln.emit.push_back(o.emit[k]);
+            ln.emit_n.push_back(o.emit_n[k]);
+            ln.emit.resize(ln.ids.size() * ln.stride);
+            for (size_t j = 0; j < o.emit_n[k]; ++j) ln.emit[(ln.ids.size() - 1) * ln.stride + j] = o.emit[k * o.stride + j];
           }
         o.ids.clear();
         o.emit.clear();
+        o.emit_n.clear();
         send_updates(o, ftab_slots != 0);  // what its last round found out
         ln.unassigned = true;     // its queries may be without tables
         merged = true;

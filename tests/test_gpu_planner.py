@@ -407,6 +407,67 @@ def test_table_budget_does_not_change_a_batch(ctx):
             assert np.array_equal(v, r[k], equal_nan=True), k
 
 
+def test_lane_merge_point_does_not_change_a_batch(ctx):
+    """When the two lanes of a large batch merge is a matter of timing (the host merges them once it
+    mostly waits for the device).  Forced to a range of turns of the round loop -- early, with
+    hundreds of queries in each lane, and late, when each query sends several nodes per round and
+    the tables of known cells are in use -- every query comes out as in the unforced run."""
+    import os
+    occ = W.plan_map(1024, 0.02)
+    m = api.ObstacleMap(ctx, raster=occ)
+    cs, cg = W.plan_queries(6000, 1024, 16, min_dist=20.0, max_dist=150.0)
+    fs = api.collision_flags(ctx, m, CONF, cs[:, 0], cs[:, 1], cs[:, 2])
+    fg = api.collision_flags(ctx, m, CONF, cg[:, 0], cg[:, 1], cg[:, 2])
+    inside = (cs[:, 0] > 8) & (cs[:, 0] < 1015) & (cs[:, 1] > 8) & (cs[:, 1] < 1015)
+    keep = np.nonzero(inside & (fs == 0) & (fg == 0))[0][:1200]
+    starts, goals = cs[keep], cg[keep]
+    ctx.set_max_expansions(1500)
+    runs = {}
+    try:
+        for turn in (None, 1, 3, 20, 70, 110, 160, 240, 400, 10 ** 6):
+            if turn is None:
+                os.environ.pop("PP_PLAN_MERGE_TURN", None)
+            else:
+                os.environ["PP_PLAN_MERGE_TURN"] = str(turn)
+            r = api.plan_batch(ctx, m, CONF, starts, goals, cap=2048, closed_cap=1500)
+            runs[turn] = {k: np.array(r[k], copy=True) for k in ("status", "len", "cost", "x", "y", "yaw", "dir", "closed")}
+            runs[turn]["exp"] = np.array([int(s.expansions) for s in r["stats"]])
+            runs[turn]["poses"] = np.array([int(s.poses_checked) for s in r["stats"]])
+            runs[turn]["rounds"] = api.plan_batch_counters(ctx)["rounds"]
+    finally:
+        os.environ.pop("PP_PLAN_MERGE_TURN", None)
+        ctx.set_max_expansions(100000)
+    ref = runs[None]
+    assert (ref["exp"] > 300).sum() >= 8, "too few long searches to outlive a late merge"
+    assert ref["rounds"] > 400, ref["rounds"]
+    for turn, r in runs.items():
+        for k, v in ref.items():
+            if k != "rounds":
+                assert np.array_equal(v, r[k], equal_nan=True), (turn, k)
+    # The same queries dealt so that one lane (the even positions) holds the short searches and is
+    # long done when the merge comes: it then takes over the other lane's queries from nothing.
+    order = np.argsort(ref["exp"], kind="stable")
+    half = len(order) // 2
+    perm = np.empty(2 * half, dtype=np.int64)
+    perm[0::2], perm[1::2] = order[:half], order[len(order) - half:]
+    lane0_last = int(ref["exp"][order[half - 1]])
+    assert lane0_last < 60, lane0_last
+    ctx.set_max_expansions(1500)
+    try:
+        for turn in (None, lane0_last + 40, 300, 700):
+            if turn is None:
+                os.environ.pop("PP_PLAN_MERGE_TURN", None)
+            else:
+                os.environ["PP_PLAN_MERGE_TURN"] = str(turn)
+            r = api.plan_batch(ctx, m, CONF, starts[perm], goals[perm], cap=2048, closed_cap=1500)
+            for k in ("status", "len", "cost", "x", "y", "yaw", "dir", "closed"):
+                assert np.array_equal(ref[k][perm], r[k], equal_nan=True), (turn, k)
+            assert np.array_equal(ref["exp"][perm], [int(s.expansions) for s in r["stats"]]), turn
+    finally:
+        os.environ.pop("PP_PLAN_MERGE_TURN", None)
+        ctx.set_max_expansions(100000)
+
+
 def test_batch_over_several_contexts_equals_one_context(ctx):
     """pp_plan_batch_multi deals the queries over contexts (one per device in a multi-GPU process;
     here three on the one card) by goal group, a host thread each, and gathers every result at its

@@ -230,8 +230,99 @@ class OpenHeap {
 // rollouts.  It is a function of the node alone, so it can be fetched before the node is closed.
 struct Expansion {
   PpShotOut shot;
-  std::vector<uint8_t> valid;   // P
-  std::unique_ptr<uint64_t[]> words;  // P records of 8 (PpExpandDev::rec), those of the valid primitives filled in
+  std::unique_ptr<uint64_t[]> words;  // P records of 8 (PpExpandDev::rec), those of the valid primitives filled in,
+                                      // and behind them the P valid bytes
+  const uint8_t* valid(uint32_t np) const { return (const uint8_t*)(words.get() + 8 * (size_t)np); }
+  uint8_t* valid(uint32_t np) { return (uint8_t*)(words.get() + 8 * (size_t)np); }
+};
+
+// A query's expansions fetched ahead of their node's turn, by node id.  A few hundred entries at
+// most, filled and emptied every round: entries live in a slab that is reused (an entry's record
+// block is allocated once), found through a small open-addressing table.
+class ExpansionCache {
+ public:
+  size_t size() const { return n_; }
+  void clear() {
+    if (n_ == 0) return;
+    std::fill(tab_.begin(), tab_.end(), Ent{-1, -1});
+    free_.clear();
+    for (int32_t s = (int32_t)slab_.size(); s-- > 0;) free_.push_back(s);
+    n_ = 0;
+  }
+  Expansion* find(int32_t id) {
+    if (n_ == 0) return nullptr;
+    for (size_t i = home(id);; i = (i + 1) & (tab_.size() - 1)) {
+      if (tab_[i].id == id) return &slab_[tab_[i].slot];
+      if (tab_[i].id < 0) return nullptr;
+    }
+  }
+  // the entry for `id` (not present so far); np = primitives per node
+  Expansion& insert(int32_t id, uint32_t np) {
+    if (np != np_) {  // another motion set than the slab was built for (between batches: the cache is empty)
+      slab_.clear();
+      free_.clear();
+      std::fill(tab_.begin(), tab_.end(), Ent{-1, -1});
+      n_ = 0;
+      np_ = np;
+    }
+    if (tab_.empty() || 2 * (n_ + 1) > tab_.size()) grow();
+    int32_t slot;
+    if (free_.empty()) {
+      slot = (int32_t)slab_.size();
+      slab_.emplace_back();
+      slab_.back().words.reset(new uint64_t[8 * (size_t)np + (np + 7) / 8]);
+    } else {
+      slot = free_.back();
+      free_.pop_back();
+    }
+    size_t i = home(id);
+    while (tab_[i].id >= 0) i = (i + 1) & (tab_.size() - 1);
+    tab_[i] = Ent{id, slot};
+    ++n_;
+    return slab_[slot];
+  }
+  void erase(int32_t id) {
+    if (n_ == 0) return;
+    const size_t mask = tab_.size() - 1;
+    size_t i = home(id);
+    while (tab_[i].id != id) {
+      if (tab_[i].id < 0) return;
+      i = (i + 1) & mask;
+    }
+    free_.push_back(tab_[i].slot);
+    --n_;
+    // close the gap: move back the entries of the run behind it that may sit closer to their home
+    for (size_t j = (i + 1) & mask; tab_[j].id >= 0; j = (j + 1) & mask) {
+      const size_t h = home(tab_[j].id);
+      if (((j - h) & mask) >= ((j - i) & mask)) {
+        tab_[i] = tab_[j];
+        i = j;
+      }
+    }
+    tab_[i] = Ent{-1, -1};
+  }
+
+ private:
+  struct Ent {
+    int32_t id, slot;
+  };
+  size_t home(int32_t id) const { return ((uint32_t)id * 2654435761u >> 7) & (tab_.size() - 1); }
+  void grow() {
+    std::vector<Ent> old;
+    old.swap(tab_);
+    tab_.assign(old.empty() ? 64 : 2 * old.size(), Ent{-1, -1});
+    for (const Ent& e : old)
+      if (e.id >= 0) {
+        size_t i = home(e.id);
+        while (tab_[i].id >= 0) i = (i + 1) & (tab_.size() - 1);
+        tab_[i] = e;
+      }
+  }
+  std::vector<Ent> tab_;
+  std::vector<Expansion> slab_;  // an entry's address is only used until the next insert
+  std::vector<int32_t> free_;
+  size_t n_ = 0;
+  uint32_t np_ = 0;
 };
 // The same data in place, in the round's staging buffer or in a cache entry.
 struct ExpansionView {
@@ -259,7 +350,7 @@ struct Query {
   std::vector<SNode> nodes;
   NodeTable tab;  // open and closed set
   OpenHeap heap;
-  std::unordered_map<int32_t, Expansion> cache;  // expansions fetched ahead of their node's turn
+  ExpansionCache cache;  // expansions fetched ahead of their node's turn
   std::vector<int32_t> want;                     // nodes to expand in this round, want[0] = curr
   int32_t status = PP_OK;
   bool live = false;
@@ -646,6 +737,9 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
 #ifndef PP_SPEC_ITEMS
 #define PP_SPEC_ITEMS 128
 #endif
+#ifndef PP_SPEC_WALK
+#define PP_SPEC_WALK 3
+#endif
 #ifndef PP_SPEC_DEPTH
 #define PP_SPEC_DEPTH 8
 #endif
@@ -765,11 +859,6 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     };
     if (so.flags & 2u) guard_band();
     if (so.flags & (4u | 8u | 16u)) {
-#ifdef PP_LAB_CHECK
-      fprintf(stderr, "[check] ctx %p query ends on shot flags %x n_paths %d idx %d gen %d cost %g handed %u pad %x at expansion %llu node %d\n",
-              (void*)ctx, so.flags, so.n_paths, so.path_idx, so.gen, so.cost, so.poses_handed, so.pad_,
-              (unsigned long long)q.st.expansions, q.curr);
-#endif
       q.status = (so.flags & 4u) ? PP_ERR_DEGENERATE_RS : (so.flags & 8u) ? PP_ERR_NAN_COST : PP_ERR_NONFINITE;
       q.live = false;
       return;
@@ -842,21 +931,21 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
       if (q.ftab >= 0) q.upd.push_back(PpFtabUpd{key, f64_bits(cost), q.ftab, 0});
     }
   };
-  auto view_of = [&](const Expansion& e) { return ExpansionView{&e.shot, e.valid.data(), e.words.get()}; };
+  auto view_of = [&](const Expansion& e) { return ExpansionView{&e.shot, e.valid(NP), e.words.get()}; };
   // Closes nodes (hybrid_astar.rs:157-161) for as long as their expansions are already at hand;
   // returns with q.curr = the node the device has to expand next, or with the query finished.
   auto advance = [&](Query& q) {
     if (!q.live) return;
     for (;;) {
       if (q.curr >= 0) {
-        auto c = q.cache.find(q.curr);
-        if (c == q.cache.end()) return;
-        if (beyond_limit(view_of(c->second))) {  // fetched before the grids were completed
-          q.cache.erase(c);
+        const Expansion* c = q.cache.find(q.curr);
+        if (!c) return;
+        if (beyond_limit(view_of(*c))) {  // fetched before the grids were completed
+          q.cache.erase(q.curr);
           return;
         }
-        apply(q, view_of(c->second));
-        q.cache.erase(c);
+        apply(q, view_of(*c));  // (the entry stays put meanwhile: apply inserts nothing)
+        q.cache.erase(q.curr);
         q.curr = -1;
         if (!q.live) return;
       }
@@ -893,7 +982,9 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
   auto speculate = [&](Query& q, size_t depth) {
     size_t frontier[132], nf = 0;
     if (q.heap.size()) frontier[nf++] = 0;
-    for (int step = 0; step < 32 && nf && q.want.size() < depth; ++step) {
+    // (a walk of three times the nodes a query may send: whatever lies deeper is several rounds away,
+    // and a walk over entries that are all fetched already is the most expensive kind)
+    for (size_t step = 0; step < PP_SPEC_WALK * depth && nf && q.want.size() < depth; ++step) {
       size_t b = 0;
       for (size_t j = 1; j < nf; ++j)
         if (HeapLess()(q.heap[frontier[b]], q.heap[frontier[j]])) b = j;
@@ -903,7 +994,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
       const NodeTable::Slot* sl = q.tab.find(q.heap[i].key);
       if (!sl || sl->state() != NodeTable::kOpen) continue;  // a stale entry
       const int32_t id = sl->node;
-      bool dup = q.cache.count(id) != 0;
+      bool dup = q.cache.find(id) != nullptr;
       for (size_t j = 1; j < q.want.size() && !dup; ++j) dup = q.want[j] == id;  // a key's older entries name the same node
       if (!dup) q.want.push_back(id);
     }
@@ -935,9 +1026,6 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     int pc = 0;
     size_t nl = 0, ni = 0, depth = 1;
     size_t r_shot = 0, r_valid = 0, r_rec = 0;
-#ifdef PP_LAB_CHECK
-    size_t r_q = 0;
-#endif
     // news for the tables of known cells, written by the workers as they apply a round
     PpFtabUpd* upd = nullptr;
     std::atomic<uint32_t> upd_n{0}, upd_fail{UINT32_MAX};  // records reserved; lowest reservation that did not fit
@@ -1199,11 +1287,6 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     ln.stride = std::min<size_t>(kSpecDepth, std::max<size_t>(1, kSpecItems / nl));
     ln.emit.resize(nl * ln.stride);
     ln.emit_n.resize(nl);
-#ifdef PP_LAB_CHECK
-    ln.r_q = r_q;
-    std::memset(h + ln.r_shot, 0xEE, ni * sizeof(PpShotOut));
-    std::memset(h + ln.r_valid, 0xEE, itn);
-#endif
     const double p2 = prof ? now_ms() : 0.0;
     ++c_rounds;
     if (nl < 64) ++c_small;
@@ -1267,24 +1350,6 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     const PpShotOut* shot = (const PpShotOut*)(h + ln.r_shot);
     const uint8_t* v_valid = (const uint8_t*)(h + ln.r_valid);
     const uint64_t* v_rec = (const uint64_t*)(h + ln.r_rec);
-#ifdef PP_LAB_CHECK
-    {
-      size_t bad_shot = 0, bad_valid = 0, first = ~(size_t)0;
-      for (size_t it = 0; it < ln.ni; ++it) {
-        if (shot[it].pad_ == 0xEEEEEEEEu || shot[it].flags > 31u || shot[it].n_paths < 0 || shot[it].n_paths > 46) {
-          ++bad_shot;
-          if (first == ~(size_t)0) first = it;
-        }
-        for (size_t i = 0; i < NP; ++i)
-          if (v_valid[it * NP + i] > 63u) ++bad_valid;
-      }
-      if (bad_shot || bad_valid)
-        fprintf(stderr, "[check] ctx %p lane %d round %u: ni %zu nl %zu stride %zu: %zu bad shots (first item %zu: flags %x n_paths %d pad %x), %zu bad valid bytes\n",
-                (void*)ctx, (int)(&ln - lanes), ln.rounds, ln.ni, ln.nl, ln.depth, bad_shot, first,
-                first != ~(size_t)0 ? shot[first].flags : 0u, first != ~(size_t)0 ? shot[first].n_paths : 0,
-                first != ~(size_t)0 ? shot[first].pad_ : 0u, bad_valid);
-    }
-#endif
     const size_t depth = ln.depth;
     pool.run(ln.nl, [&](size_t k) {
       Query& q = Q[ln.ids[k]];
@@ -1294,12 +1359,11 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
       if (q.cache.size() > kCacheMax) q.cache.clear();
       for (size_t j = 1; j < q.want.size(); ++j) {
         const size_t it = first + j;
-        Expansion& e = q.cache[q.want[j]];
+        Expansion& e = q.cache.insert(q.want[j], NP);
         e.shot = shot[it];
-        e.valid.assign(v_valid + it * NP, v_valid + (it + 1) * NP);
-        if (!e.words) e.words.reset(new uint64_t[8 * (size_t)NP]);
+        std::memcpy(e.valid(NP), v_valid + it * NP, NP);
         for (uint32_t i = 0; i < NP; ++i)
-          if (e.valid[i] & 1u) std::memcpy(e.words.get() + 8 * (size_t)i, v_rec + 8 * (it * NP + i), 64);
+          if (v_valid[it * NP + i] & 1u) std::memcpy(e.words.get() + 8 * (size_t)i, v_rec + 8 * (it * NP + i), 64);
       }
       // the next query's results (written by the device: in no cache) and the query itself
       if (depth == 1 && k + 1 < ln.nl) {
@@ -1310,17 +1374,6 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
         for (size_t o = 0; o < sizeof(Query); o += 64) __builtin_prefetch(qn + o);
       }
       const size_t it = first, b = it * NP;
-#ifdef PP_LAB_CHECK
-      for (size_t j = 0; j < q.want.size(); ++j)
-        if (shot[first + j].flags & 4u) {
-          const double* hq = (const double*)(h + ln.r_q);
-          const SNode& n = q.nodes[q.want[j]];
-          const size_t i2 = first + j;
-          fprintf(stderr, "[check] lane %d round %u item %zu (+%zu of %zu) ni %zu: staged start %.17g %.17g %.17g goal %.17g %.17g %.17g | node %.17g %.17g %.17g goal %.17g %.17g %.17g\n",
-                  (int)(&ln - lanes), ln.rounds, i2, j, q.want.size(), ln.ni, hq[i2], hq[ln.ni + i2], hq[2 * ln.ni + i2],
-                  hq[3 * ln.ni + i2], hq[4 * ln.ni + i2], hq[5 * ln.ni + i2], n.x, n.y, n.yaw, q.goal[0], q.goal[1], q.goal[2]);
-        }
-#endif
       const ExpansionView v{&shot[it], v_valid + b, v_rec + 8 * b};
       if (beyond_limit(v)) {
         need_grids.store(true, std::memory_order_relaxed);  // q.curr stays: the node goes to the device again

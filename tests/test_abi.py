@@ -25,6 +25,27 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(lib._pp_symbols)
 
 
+def test_rust_sys_covers_the_header():
+    """rust/path_planner_hip/src/sys.rs (never compiled here: the image has no rustc) declares exactly
+    the functions of include/pp.h, each with as many arguments as the header gives it."""
+    hdr = open(os.path.join(ROOT, "include", "pp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    rs = open(os.path.join(ROOT, "rust", "path_planner_hip", "src", "sys.rs")).read()
+    rs = re.sub(r"//[^\n]*", "", rs)
+
+    def arity(args):
+        args = args.strip()
+        return 0 if args in ("", "void") else args.count(",") + 1
+
+    c_fns = {m.group(1): arity(m.group(2)) for m in re.finditer(r"\b(pp_[a-z_0-9]+)\s*\(([^()]*)\)\s*;", hdr)}
+    rs_fns = {m.group(1): arity(m.group(2).rstrip().rstrip(","))
+              for m in re.finditer(r"pub fn (pp_[a-z_0-9]+)\(([^()]*)\)", rs)}
+    assert len(c_fns) >= 50
+    assert set(c_fns) == set(rs_fns), set(c_fns) ^ set(rs_fns)
+    for name, n in c_fns.items():
+        assert rs_fns[name] == n, (name, n, rs_fns[name])
+
+
 def test_struct_layouts_match_header_sizes():
     assert C.sizeof(A.Car) == 32 and C.sizeof(A.Config) == 128
     assert C.sizeof(A.Param) == 72 and C.sizeof(A.RsWord) == 56

@@ -168,6 +168,9 @@ def load_library(path=None):
         "pp_slab_gather": (C.c_int32, [vp, C.c_uint64, vp, vp, vp]),
         "pp_slab_reset": (C.c_int32, [vp, vp]),
         "pp_slab_destroy": (None, [vp]),
+        "pp_slab_relax_all": (C.c_int32, [C.POINTER(vp), C.c_uint32, C.c_double, u64]),
+        "pp_wavefront_tiled": (C.c_int32, [C.POINTER(vp), C.c_uint32, C.c_uint64, C.c_uint64, u8, C.c_uint64,
+                                           C.c_uint64, d, C.c_double, u64]),
         "pp_rs_batch": (C.c_int32, [vp, C.c_uint64, d, d, d, d, d, d, C.c_double, i32, i32,
                                     C.POINTER(RsWord), u8]),
         "pp_rs_words_batch": (C.c_int32, [vp, C.c_uint64, d, d, d, d, d, d, C.c_double, i32,

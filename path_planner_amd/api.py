@@ -234,6 +234,20 @@ def wavefront_dev(ctx, obs, goal_x, goal_y, cost):
     return iters.value
 
 
+def wavefront_tiled(ctxs, obs, goal_x, goal_y, band=0.0):
+    """astar.rs:153-198 on a host raster obs[x, y] (uint8, non-zero = blocked) cut into column slabs
+    over the contexts of this process (pp_wavefront_tiled).  Returns (cost[x, y] float64, exchange
+    rounds)."""
+    obs = np.ascontiguousarray(obs, dtype=np.uint8)
+    xw, yw = obs.shape
+    cost = np.empty((xw, yw), np.float64)
+    rounds = C.c_uint64(0)
+    hc = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    _chk(ctxs[0].lib.pp_wavefront_tiled(hc, len(ctxs), xw, yw, _p(obs, C.c_uint8), goal_x, goal_y, _p(cost),
+                                        float(band), C.byref(rounds)), "pp_wavefront_tiled")
+    return cost, rounds.value
+
+
 def wavefront_stats(ctx):
     out = np.zeros(4, np.uint64)
     _chk(ctx.lib.pp_wavefront_stats(ctx.h, _p(out, C.c_uint64)), "pp_wavefront_stats")

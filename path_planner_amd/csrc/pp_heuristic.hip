@@ -9,6 +9,10 @@
 // rounds ordered by the lowest value waiting at each tile.
 #include <cstdio>
 #include <algorithm>
+#include <system_error>
+#include <thread>
+#include <vector>
+#include <cstring>
 
 #include "pp_internal.h"
 
@@ -1462,6 +1466,189 @@ extern "C" int32_t pp_slab_read(pp_slab* s, double* d_cost_slab) {
   PP_HIP(ctx, hipGetLastError());
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PP_OK;
+}
+
+// ------------------------------------------------------------------ slabs of one process, driven together
+// The exchange loop a multi-GPU driver runs over its ranks' slab sessions, for the sessions of one
+// process (one context per device): every round each slab relaxes what it has pending up to the
+// limit, on a host thread of its own, neighbours' boundary columns are copied across, and the
+// lowest value pending anywhere plus `band` is the next limit.  The fixpoint does not depend on
+// the schedule, so the slabs end up holding the costs a single relaxation of the whole raster
+// gives.
+extern "C" int32_t pp_slab_relax_all(pp_slab* const* slabs, uint32_t n, double band, uint64_t* rounds_out) {
+  if (!slabs || n == 0 || band != band) return PP_ERR_INVALID;
+  if (!(band > 0.0)) band = 1024.0;
+  for (uint32_t k = 0; k < n; ++k) {
+    if (!slabs[k] || !slabs[k]->ctx) return PP_ERR_INVALID;
+    for (uint32_t j = 0; j < k; ++j)
+      if (slabs[j] == slabs[k] || slabs[j]->ctx == slabs[k]->ctx) return PP_ERR_INVALID;  // a context drives one slab
+    if (slabs[k]->d.yw != slabs[0]->d.yw) return PP_ERR_INVALID;
+    // column order, no gap: slab k's first owned column follows slab k - 1's last
+    if (k && slabs[k]->d.gx_off + 1 != slabs[k - 1]->d.gx_off + (int64_t)slabs[k - 1]->d.ncols - 1) return PP_ERR_INVALID;
+  }
+  const uint64_t yw = slabs[0]->d.yw;
+  const double inf = __builtin_inf();
+  struct Side {
+    double *edge_lo = nullptr, *edge_hi = nullptr, *halo_lo = nullptr, *halo_hi = nullptr;
+  };
+  std::vector<Side> side(n);
+  auto release = [&] {
+    for (uint32_t k = 0; k < n; ++k) {
+      (void)hipSetDevice(slabs[k]->ctx->device);
+      for (double* p : {side[k].edge_lo, side[k].edge_hi, side[k].halo_lo, side[k].halo_hi})
+        if (p) (void)hipFree(p);
+    }
+  };
+  auto fail = [&](int32_t code) {
+    release();
+    return code;
+  };
+  for (uint32_t k = 0; k < n; ++k) {
+    pp_ctx* ctx = slabs[k]->ctx;
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(PP_ERR_HIP);
+    // a side with no neighbour has no edge buffer: its values are nobody's halo
+    for (double** p : {k > 0 ? &side[k].edge_lo : nullptr, k + 1 < n ? &side[k].edge_hi : nullptr,
+                       k > 0 ? &side[k].halo_lo : nullptr, k + 1 < n ? &side[k].halo_hi : nullptr}) {
+      if (!p) continue;
+      const hipError_t e = hipMalloc((void**)p, yw * 8);
+      if (e != hipSuccess) {
+        ctx->last_hip_error = (int32_t)e;
+        (void)hipGetLastError();
+        return fail(PP_ERR_HIP);
+      }
+      hipLaunchKernelGGL(k_fill_inf, dim3((unsigned)std::min<uint64_t>((yw + 255) / 256, 1024)), dim3(256), 0,
+                         ctx->stream, *p, yw);
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(PP_ERR_HIP);
+  }
+  std::vector<double> pending(n, inf);
+  std::vector<int32_t> status(n, PP_OK);
+  double limit = band;  // the goal's cost is 0
+  bool first = true;
+  uint64_t rounds = 0;
+  for (;; ++rounds) {
+    if (rounds > ((uint64_t)1 << 24)) return fail(PP_ERR_UNSUPPORTED);
+    auto relax = [&](uint32_t k) {
+      try {
+        status[k] = pp_slab_relax(slabs[k], first ? nullptr : side[k].halo_lo, first ? nullptr : side[k].halo_hi, limit,
+                                  side[k].edge_lo, side[k].edge_hi, &pending[k], nullptr);
+      } catch (...) {
+        status[k] = PP_ERR_UNSUPPORTED;
+      }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t k = 1; k < n; ++k) {
+      try {
+        th.emplace_back(relax, k);
+      } catch (const std::system_error&) {
+        relax(k);  // no thread to be had: this slab's turn runs here
+      }
+    }
+    relax(0);
+    for (std::thread& t : th) t.join();
+    for (uint32_t k = 0; k < n; ++k)
+      if (status[k] != PP_OK) return fail(status[k]);
+    first = false;
+    const double lowest = *std::min_element(pending.begin(), pending.end());
+    if (lowest == inf) {
+      ++rounds;
+      break;
+    }
+    limit = lowest + band;
+    // every relax has waited for its stream, so the edge columns are in place: across they go
+    for (uint32_t k = 0; k + 1 < n; ++k) {
+      pp_ctx *a = slabs[k]->ctx, *b = slabs[k + 1]->ctx;
+      hipError_t e;
+      if (a->device == b->device) {
+        (void)hipSetDevice(a->device);
+        e = hipMemcpy(side[k + 1].halo_lo, side[k].edge_hi, yw * 8, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(side[k].halo_hi, side[k + 1].edge_lo, yw * 8, hipMemcpyDeviceToDevice);
+      } else {
+        e = hipMemcpyPeer(side[k + 1].halo_lo, b->device, side[k].edge_hi, a->device, yw * 8);
+        if (e == hipSuccess) e = hipMemcpyPeer(side[k].halo_hi, a->device, side[k + 1].edge_lo, b->device, yw * 8);
+      }
+      if (e != hipSuccess) {
+        a->last_hip_error = (int32_t)e;
+        (void)hipGetLastError();
+        return fail(PP_ERR_HIP);
+      }
+    }
+  }
+  release();
+  if (rounds_out) *rounds_out = rounds;
+  return PP_OK;
+}
+
+// Columns [begin, end) of slab `rank` out of `world` over xw columns: contiguous, sizes differ by at most one.
+static void slab_bounds(uint64_t xw, uint32_t world, uint32_t rank, uint64_t* begin, uint64_t* end) {
+  const uint64_t base = xw / world, rem = xw % world;
+  *begin = rank * base + std::min<uint64_t>(rank, rem);
+  *end = *begin + base + (rank < rem ? 1 : 0);
+}
+
+extern "C" int32_t pp_wavefront_tiled(pp_ctx* const* ctxs, uint32_t n_ctx, uint64_t xw, uint64_t yw,
+                                      const uint8_t* obs, uint64_t goal_x, uint64_t goal_y, double* cost,
+                                      double band, uint64_t* rounds) {
+  if (!ctxs || n_ctx == 0 || !obs || !cost) return PP_ERR_INVALID;
+  for (uint32_t k = 0; k < n_ctx; ++k) {
+    if (!ctxs[k]) return PP_ERR_INVALID;
+    for (uint32_t j = 0; j < k; ++j)
+      if (ctxs[j] == ctxs[k]) return PP_ERR_INVALID;
+  }
+  if (xw == 0 || yw == 0 || xw >= ((uint64_t)1 << 31) || yw >= ((uint64_t)1 << 31)) return PP_ERR_UNSUPPORTED;
+  if (goal_x >= xw || goal_y >= yw) return PP_ERR_BOUNDS;
+  if (n_ctx > xw) return PP_ERR_INVALID;  // a slab owns at least one column
+  std::vector<pp_slab*> slabs(n_ctx, nullptr);
+  auto leave = [&](int32_t code) {
+    for (pp_slab* s : slabs) pp_slab_destroy(s);
+    return code;
+  };
+  std::vector<uint8_t> hs;
+  for (uint32_t k = 0; k < n_ctx; ++k) {
+    pp_ctx* ctx = ctxs[k];
+    uint64_t x0, x1;
+    slab_bounds(xw, n_ctx, k, &x0, &x1);
+    const uint64_t ncols = x1 - x0 + 2;
+    // the slab's raster with one halo column each side, blocked outside the grid
+    hs.assign(ncols * yw, 1);
+    const uint64_t lo = x0 ? x0 - 1 : 0, hi = std::min(x1 + 1, xw);
+    std::memcpy(hs.data() + (lo - (x0 - 1)) * yw, obs + lo * yw, (hi - lo) * yw);
+    if (hipSetDevice(ctx->device) != hipSuccess) return leave(PP_ERR_HIP);
+    uint8_t* d_obs = nullptr;
+    hipError_t e = hipMalloc((void**)&d_obs, hs.size());
+    if (e == hipSuccess) e = hipMemcpy(d_obs, hs.data(), hs.size(), hipMemcpyHostToDevice);
+    int32_t st = PP_ERR_HIP;
+    if (e == hipSuccess) st = pp_slab_create(ctx, xw, yw, x0, x1, d_obs, goal_x, goal_y, &slabs[k]);
+    else ctx->last_hip_error = (int32_t)e, (void)hipGetLastError();
+    if (d_obs) (void)hipFree(d_obs);  // packed: the session holds its own copy
+    if (st != PP_OK) return leave(st);
+  }
+  int32_t st = pp_slab_relax_all(slabs.data(), n_ctx, band, rounds);
+  if (st != PP_OK) return leave(st);
+  for (uint32_t k = 0; k < n_ctx; ++k) {
+    pp_ctx* ctx = ctxs[k];
+    uint64_t x0, x1;
+    slab_bounds(xw, n_ctx, k, &x0, &x1);
+    const uint64_t ncols = x1 - x0 + 2;
+    if (hipSetDevice(ctx->device) != hipSuccess) return leave(PP_ERR_HIP);
+    double* d_cost = nullptr;
+    hipError_t e = hipMalloc((void**)&d_cost, ncols * yw * 8);
+    if (e != hipSuccess) {
+      ctx->last_hip_error = (int32_t)e;
+      (void)hipGetLastError();
+      return leave(PP_ERR_HIP);
+    }
+    st = pp_slab_read(slabs[k], d_cost);
+    if (st == PP_OK)  // the owned columns only
+      e = hipMemcpy(cost + x0 * yw, d_cost + yw, (x1 - x0) * yw * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_cost);
+    if (st != PP_OK) return leave(st);
+    if (e != hipSuccess) {
+      ctx->last_hip_error = (int32_t)e;
+      return leave(PP_ERR_HIP);
+    }
+  }
+  return leave(PP_OK);
 }
 
 // calc_parameters of astar.rs:232-242 on the obstacle lists scaled by 1/reso.

@@ -209,6 +209,11 @@ extern "C" {
     pub fn pp_slab_read(slab: *mut pp_slab, d_cost_slab: *mut f64) -> i32;
     pub fn pp_slab_gather(slab: *mut pp_slab, n: u64, d_x: *const u64, d_y: *const u64, d_out: *mut f64) -> i32;
     pub fn pp_slab_destroy(slab: *mut pp_slab);
+    pub fn pp_slab_relax_all(slabs: *const *mut pp_slab, n: u32, band: f64, rounds: *mut u64) -> i32;
+    pub fn pp_wavefront_tiled(
+        ctxs: *const *mut pp_ctx, n_ctx: u32, xw: u64, yw: u64, obs: *const u8, goal_x: u64, goal_y: u64,
+        cost: *mut f64, band: f64, rounds: *mut u64,
+    ) -> i32;
 
     // Reeds-Shepp
     pub fn pp_rs_batch(

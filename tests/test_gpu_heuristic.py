@@ -276,6 +276,37 @@ def test_whole_grid_session_equals_the_dense_entry_point(ctx):
     sess.close()
 
 
+@pytest.mark.parametrize("xw,yw,nctx,band", [(300, 300, 2, 0.0), (300, 300, 3, 16.0), (257, 130, 3, 1.0),
+                                              (5, 40, 5, 0.0), (700, 512, 4, 64.0), (64, 64, 1, 0.0)])
+def test_wavefront_tiled_over_contexts_equals_one_relaxation(ctx, xw, yw, nctx, band):
+    """pp_wavefront_tiled cuts the raster into column slabs, one per context (here: several
+    contexts on the one GPU, as the devices of a node would be), relaxes them in cost order with
+    their boundary columns copied across, and gives the costs of one relaxation of the whole
+    raster -- the oracle's, bit for bit -- whatever the number of slabs and the band."""
+    u = W.uniform01(77 + xw * 1000 + yw, 0, xw * yw).reshape(xw, yw)
+    obs = (u < 0.25).astype(np.uint8)
+    gx, gy = (3 * xw) // 4, yw // 3  # off-centre: the goal's slab is not the middle one
+    obs[gx, gy] = 0
+    ctxs = [ctx] + [api.Context(0) for _ in range(nctx - 1)]
+    try:
+        cost, rounds = api.wavefront_tiled(ctxs, obs, gx, gy, band)
+        st, exp = O.wavefront(obs, gx, gy)
+        assert st == 0
+        same_grid(cost, exp)
+        assert rounds >= 1
+        if nctx > 1 and band and band <= 16.0 and xw >= 257:
+            assert rounds > 3, rounds  # a narrow band takes many exchanges to the same result
+        # errors: the same context twice, more slabs than columns, a goal outside
+        if nctx > 1:
+            with pytest.raises(api.PlannerError):
+                api.wavefront_tiled([ctx, ctx], obs, gx, gy)
+        with pytest.raises(api.PlannerError):
+            api.wavefront_tiled(ctxs, obs[:max(1, nctx - 1)], 0, 0) if nctx > 1 else api.wavefront_tiled(ctxs, obs, xw, 0)
+    finally:
+        for c in ctxs[1:]:
+            c.close()
+
+
 def test_slab_outlives_its_context():
     """A context destroyed before its slab session takes the slab's device memory with it: the
     handle then refuses every call and pp_slab_destroy still works (two sessions, one destroyed in

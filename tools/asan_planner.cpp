@@ -58,6 +58,25 @@ int main(int argc, char** argv) {
     for (int i = 0; i < nq; ++i) { ok += status[i] == 0; lim += status[i] == -11; ex += stats[i].expansions; }
     printf("rep %d rc %d: %d queries, %ld found, %ld at the cap, %llu expansions\n", rep, rc, nq, ok, lim, ex);
   }
+  {  // the heuristic grid in column slabs over three contexts, a host thread each
+    const uint64_t xw = 301, yw = 257;
+    std::vector<uint8_t> obs(xw * yw, 0);
+    for (uint64_t i = 0; i < xw * yw; ++i) obs[i] = (rng() % 100) < 22;
+    obs[200 * yw + 90] = 0;
+    std::vector<double> one(xw * yw), three(xw * yw);
+    pp_ctx *c2 = nullptr, *c3 = nullptr;
+    if (pp_ctx_create(0, nullptr, &c2) != 0 || pp_ctx_create(0, nullptr, &c3) != 0) return 4;
+    pp_ctx* all[3] = {ctx, c2, c3};
+    uint64_t r1 = 0, r3 = 0;
+    const int32_t a = pp_wavefront_tiled(all, 1, xw, yw, obs.data(), 200, 90, one.data(), 0.0, &r1);
+    const int32_t b = pp_wavefront_tiled(all, 3, xw, yw, obs.data(), 200, 90, three.data(), 8.0, &r3);
+    size_t differ = 0;
+    for (uint64_t i = 0; i < xw * yw; ++i) differ += !(one[i] == three[i]);
+    printf("tiled rc %d %d: %llu and %llu exchange rounds, %zu cells differ\n", a, b, (unsigned long long)r1,
+           (unsigned long long)r3, differ);
+    pp_ctx_destroy(c3);
+    pp_ctx_destroy(c2);
+  }
   pp_map_destroy(map);
   pp_ctx_destroy(ctx);
   printf("done\n");

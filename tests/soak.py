@@ -82,7 +82,18 @@ for r in range(rounds):
     st, ref = O.wavefront(obs, gx, gy)
     assert st == 0
     assert (d_cost.cpu().numpy().view(np.uint64) == ref.view(np.uint64)).all()
-    say(f"round {r}: wavefront {xw}x{yw}: bitwise equal, {int(np.isfinite(ref).sum())} cells reached")
+    # the same raster in column slabs over several contexts of this process
+    nslab = int(rng.integers(2, 5))
+    band = float(rng.choice([0.0, 4.0, 64.0, 700.0]))
+    helpers = [api.Context(0) for _ in range(nslab - 1)]
+    try:
+        tcost, trounds = api.wavefront_tiled([ctx] + helpers, obs, gx, gy, band)
+    finally:
+        for h in helpers:
+            h.close()
+    assert (tcost.view(np.uint64) == ref.view(np.uint64)).all()
+    say(f"round {r}: wavefront {xw}x{yw}: bitwise equal, {int(np.isfinite(ref).sum())} cells reached; "
+        f"{nslab} slabs, band {band:g}: equal after {trounds} exchange rounds")
 
     # ---- planner: a batch on a random map against the oracle, closing order and path
     msz = int(rng.integers(90, 200))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence (GPU box).  One bench line and one `rocprofv3 --kernel-trace --stats` run per
+# Evidence for the profiles directory (GPU box).  One bench line and one `rocprofv3 --kernel-trace --stats` run per
 # workload, each with --no-extra so that a CSV holds only that leg's launches, plus the counter
 # passes: the planner's fused round kernel (k_round) on the search-heavy leg, the Reeds-Shepp batch
 # kernel's instruction-cache and issue counters, and the collision kernel's HBM bytes.

@@ -69,7 +69,7 @@ __device__ inline void write_word(pp_rs_word* o, uint32_t word, int n, const dou
 // Two waves per SIMD measured best for this register-hungry kernel (1.68 G pairs/s; the compiler's
 // own choice of one wave gives 1.1, three waves spill and give 1.4, four 0.97).
 #ifndef PP_RS_BATCH_WAVES
-#define PP_RS_BATCH_WAVES 2
+#define PP_RS_BATCH_WAVES 3
 #endif
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(PP_RS_BATCH_WAVES, PP_RS_BATCH_WAVES)))
 k_rs_batch(uint64_t n, const double* __restrict__ sx, const double* __restrict__ sy,
@@ -77,18 +77,26 @@ k_rs_batch(uint64_t n, const double* __restrict__ sx, const double* __restrict__
            const double* __restrict__ gy, const double* __restrict__ gyaw, double maxc,
            int32_t* __restrict__ n_paths, int32_t* __restrict__ best_idx,
            pp_rs_word* __restrict__ best, uint8_t* __restrict__ flags) {
-  // the lane's sixteen polar forms (pp_polar_fill): 256 bytes a lane, the doubles of one kind side by side
-  __shared__ double polar[32 * 128];
-  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  // each wave's areas for the formulas it evaluates apart (pp_rs_generate_wave)
+  __shared__ __attribute__((aligned(16))) unsigned char area[2][(kRsDeferredBytes + 15) & ~(size_t)15];
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned char* const mine = area[threadIdx.x >> 6];
+  PpRsDeferred D;
+  D.pin = (double*)mine;
+  D.out = D.pin + 7 * 64;
+  D.flag = (uint8_t*)(D.out + kRsDeferredSlots * 3 * 64);
+  D.queue = (uint16_t*)(D.flag + kRsDeferredSlots * 64);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  // a wave goes round as long as any of its lanes has a pair: the lanes work on one another's candidates
+  for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+    const bool have = i0 + lane < n;
+    const uint64_t i = have ? i0 + lane : n - 1;  // a lane without a pair repeats the last one and stores nothing
     PpRsState S;
     BestSink sink;
     sink.maxc = maxc;
     const PpRsInput in = pp_rs_input(sx[i], sy[i], syaw[i], gx[i], gy[i], gyaw[i], maxc);
-    pp_polar_fill(in, polar + threadIdx.x, 128);
-    S.polar = polar + threadIdx.x;  // only this lane reads what it wrote: no barrier
-    S.polar_stride = 128;
-    pp_rs_generate_compact(in, S, sink);
+    pp_rs_generate_wave(in, S, D, lane, sink);
+    if (!have) continue;
     int np = __popcll(S.accepted);
     if (S.degenerate) {  // the reference panics inside generate_path: no paths reported
       n_paths[i] = 0;

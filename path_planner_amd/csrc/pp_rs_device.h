@@ -270,10 +270,6 @@ struct PpRsState {
   PpAmb A{false};
   bool degenerate = false;  // assert!(total_length >= 0.01) would fire (:157)
   uint64_t accepted = 0;    // bit i: candidate with generation index i became a path
-  // optional: the pair's sixteen polar forms, computed ahead by pp_polar_fill: entry
-  // e = ((back ? 4 : 0) + image) * 2 + set has rho at polar[2 e * polar_stride], theta one stride on
-  const double* polar = nullptr;
-  uint32_t polar_stride = 0;
 };
 
 // set_path, :130-159, for one candidate of word set `ws`.
@@ -348,15 +344,7 @@ __device__ __forceinline__ void pp_candidate(PpRsState& S, const PpRsInput& in, 
   const double sp = negphi ? -in.sp : in.sp;
   PpPolar pol{0.0, 0.0};
   constexpr int SET = pp_formula_set<F>();
-  if constexpr (SET >= 0) {
-    if (S.polar) {
-      constexpr int e = ((BACK ? 4 : 0) + K) * 2 + SET;
-      pol.rho = S.polar[(size_t)(2 * e) * S.polar_stride];
-      pol.th = S.polar[(size_t)(2 * e + 1) * S.polar_stride];
-    } else {
-      pol = pp_polar_set(ax, ay, sp, in.cp, SET);
-    }
-  }
+  if constexpr (SET >= 0) pol = pp_polar_set(ax, ay, sp, in.cp, SET);
   PpTuv r = pp_eval<F>(ax, ay, ap, sp, in.cp, pol, S.A);
   if (!r.ok) return;
   const double H = 0.5 * PP_RS_PI;
@@ -398,21 +386,6 @@ __device__ __forceinline__ PpRsInput pp_rs_input(double sx, double sy, double sy
   in.xb = in.x * in.cp + in.y * in.sp;  // :294-295, :482-483
   in.yb = in.x * in.sp - in.y * in.cp;
   return in;
-}
-
-// The sixteen polar forms of a pair, stored `stride` doubles apart (see PpRsState::polar): straight
-// line code, every lane busy, instead of thirty-six hypot / atan2 pairs inside the formulas' branches.
-__device__ __forceinline__ void pp_polar_fill(const PpRsInput& in, double* out, uint32_t stride) {
-#pragma unroll 2
-  for (int e = 0; e < 16; ++e) {
-    const int set = e & 1, K = (e >> 1) & 3, back = e >> 3;
-    const double bx = back ? in.xb : in.x, by = back ? in.yb : in.y;
-    const double ax = (K & 1) ? -bx : bx, ay = (K & 2) ? -by : by;
-    const double sp = (K == 1 || K == 2) ? -in.sp : in.sp;
-    const PpPolar p = pp_polar_set(ax, ay, sp, in.cp, set);
-    out[(size_t)(2 * e) * stride] = p.rho;
-    out[(size_t)(2 * e + 1) * stride] = p.th;
-  }
 }
 
 // The 46 candidates fall into seven families whose duplicate tests (set_path compares only paths
@@ -639,9 +612,36 @@ __device__ __forceinline__ unsigned long long pp_rs_commit_set(int ws, const PpR
 // swapped, and image K + 1 is image K with x and phi negated and the lengths' signs flipped; a
 // word set lives across the two images of a pair (and across the two formulas that share a word),
 // exactly as in pp_rs_group.
+// The polar forms (pp_polar_set) of images 2h and 2h + 1 of one point: the second image's point is
+// the first one's mirrored in x (same y, x negated -- both coordinates are formed here exactly as
+// pp_polar_set forms them), so the two share rho, and atan2(y, -x) is pi - atan2(y, x) rounded
+// once, which is how the library's atan2 itself gets there: with a0 = atan2(|y|, |x|),
+// atan2(y, x) = copysign(x negative ? pi - a0 : a0, y) bit for bit (checked on 2^33 random points
+// of four magnitude regimes), zeros of either sign included.  One atan2 and one square root for two.
+struct PpPolarPair {
+  double rho, th[2];
+};
+template <int SET>
+__device__ __forceinline__ PpPolarPair pp_polar_pair(double bx, double by, double sphi, double cp, int h) {
+  // images 2h / 2h + 1: x as is / negated, y negated for h = 1, sin(phi) negated for images 1 and 2
+  const double ay = h ? -by : by;
+  const double sp_e = h ? -sphi : sphi, sp_o = h ? sphi : -sphi;
+  const double px_e = SET ? bx + sp_e : bx - sp_e;
+  const double px_o = SET ? -bx + sp_o : -bx - sp_o;
+  const double py = SET ? ay - 1.0 - cp : ay - 1.0 + cp;
+  const double a0 = pp_atan2(fabs(py), fabs(px_e)), a1 = PP_RS_PI - a0;
+  PpPolarPair r;
+  r.rho = sqrt(px_e * px_e + py * py);
+  r.th[0] = copysign(signbit(px_e) ? a1 : a0, py);
+  r.th[1] = copysign(signbit(px_o) ? a1 : a0, py);
+  return r;
+}
+
+// P (optional): the polar forms of this h, entry (BACK ? 2 : 0) + set.
 template <int F, bool BACK, int LAY, int N, class Sink>
 __device__ __forceinline__ void pp_candidate_rt(PpRsState& S, const PpRsInput& in, PpWordSet<N>& ws, int K,
-                                                int gen, uint32_t word_k0, Sink& sink) {
+                                                int gen, uint32_t word_k0, Sink& sink,
+                                                const PpPolarPair* P = nullptr) {
   const double bx = BACK ? in.xb : in.x, by = BACK ? in.yb : in.y;
   const double ax = (K & 1) ? -bx : bx;
   const double ay = (K & 2) ? -by : by;
@@ -651,9 +651,12 @@ __device__ __forceinline__ void pp_candidate_rt(PpRsState& S, const PpRsInput& i
   PpPolar pol{0.0, 0.0};
   constexpr int SET = pp_formula_set<F>();
   if constexpr (SET >= 0) {
-    const int e = ((BACK ? 4 : 0) + K) * 2 + SET;
-    pol.rho = S.polar[(size_t)(2 * e) * S.polar_stride];
-    pol.th = S.polar[(size_t)(2 * e + 1) * S.polar_stride];
+    if (P) {
+      pol.rho = P[(BACK ? 2 : 0) + SET].rho;
+      pol.th = P[(BACK ? 2 : 0) + SET].th[K & 1];
+    } else {
+      pol = pp_polar_set(ax, ay, sp, in.cp, SET);
+    }
   }
   PpTuv r = pp_eval<F>(ax, ay, ap, sp, in.cp, pol, S.A);
   if (!r.ok) return;
@@ -677,52 +680,203 @@ __device__ __forceinline__ void pp_candidate_rt(PpRsState& S, const PpRsInput& i
 // Images 2h and 2h + 1 of one formula, offered to one word set.
 template <int F, bool BACK, int LAY, int N, class Sink>
 __device__ __forceinline__ void pp_pair_rt(PpRsState& S, const PpRsInput& in, PpWordSet<N>& ws, int h, int gen0,
-                                           uint32_t word_k0, Sink& sink) {
+                                           uint32_t word_k0, Sink& sink, const PpPolarPair* P = nullptr) {
   // unrolled: as a loop the two images keep every word set of the enclosing block in registers at
   // once (a few hundred spilled registers, 0.63 -> 0.82 ms per million pairs)
 #pragma unroll
-  for (int f = 0; f < 2; ++f) pp_candidate_rt<F, BACK, LAY, N>(S, in, ws, 2 * h + f, gen0 + 2 * h + f, word_k0, sink);
+  for (int f = 0; f < 2; ++f) pp_candidate_rt<F, BACK, LAY, N>(S, in, ws, 2 * h + f, gen0 + 2 * h + f, word_k0, sink, P);
 }
 
-// generate_path with S.polar filled in (pp_polar_fill); candidates reach the sink word by word,
-// not in generation order.
+// ---------------------------------------------------------------------------------------------
+// The same 46 candidates for a wave of 64 pairs, with the three formulas that only apply to nearby
+// goals evaluated apart.  lrl (:188-200), lrlrn (:334-347) and lrlrp (:349-364) start with a range
+// test -- the goal within four turning radii or so -- that few pairs of a typical batch pass, yet
+// a wave runs a formula's body (an asin, or an acos, two sincos, an atan2 and a cos) whenever one of
+// its 64 lanes does: sixteen bodies for a lane or two each.  Here a lane only takes the range test
+// and, if it passes, leaves a note (lane, candidate) in the wave's queue; the queue is then worked
+// off by all lanes side by side, one body per 64 notes, and every lane picks up its results and
+// offers them to set_path in generation order.  The formulas see the same inputs through the same
+// code, so the words are the same to the last bit.
+struct PpRsDeferred {  // the wave's areas in LDS
+  double* pin;         // [7][64]: x, y, phi, sin phi, cos phi, xb, yb of the lanes' pairs
+  double* out;         // [8][3][64]: t, u, v of candidate j of a batch, by lane
+  uint8_t* flag;       // [8][64]: bit0 the formula accepted, bit1 a comparison fell into the guard band
+  uint16_t* queue;     // [512]: lane | j << 6
+};
+#ifndef PP_RS_LRL_ONE
+constexpr int kRsDeferredSlots = 4;
+#else
+constexpr int kRsDeferredSlots = 8;
+#endif
+constexpr size_t kRsDeferredBytes = (7 * 64 + kRsDeferredSlots * 3 * 64) * 8 + kRsDeferredSlots * 64 + kRsDeferredSlots * 64 * 2;
+
+__device__ __forceinline__ void pp_wave_sync() {
+  // the lanes of a wave run in lock step; this keeps the compiler from moving LDS accesses across
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// Works off `count` notes: formula F on image j & 3 of the note's lane, for lrl on the backwards
+// point when j >= 4.
+template <int F>
+__device__ __forceinline__ void pp_deferred_eval(const PpRsDeferred& D, uint32_t count, uint32_t lane) {
+  for (uint32_t it = lane; it < count; it += 64u) {
+    const uint32_t e = D.queue[it], owner = e & 63u, j = e >> 6;
+    const bool back = F == PP_F_LRL_ && j >= 4u;
+    const int K = (int)(j & 3u);
+    const double bx = D.pin[(back ? 5 : 0) * 64 + owner], by = D.pin[(back ? 6 : 1) * 64 + owner];
+    const double phi = D.pin[2 * 64 + owner], sphi = D.pin[3 * 64 + owner], cp = D.pin[4 * 64 + owner];
+    const double ax = (K & 1) ? -bx : bx;
+    const double ay = (K & 2) ? -by : by;
+    const bool negphi = (K == 1 || K == 2);
+    const double ap = negphi ? -phi : phi;
+    const double sp = negphi ? -sphi : sphi;
+    PpPolar pol{0.0, 0.0};
+    constexpr int SET = pp_formula_set<F>();
+    if constexpr (SET >= 0) pol = pp_polar_set(ax, ay, sp, cp, SET);
+    PpAmb A{false};
+    const PpTuv r = pp_eval<F>(ax, ay, ap, sp, cp, pol, A);
+    const uint32_t sl = j & (uint32_t)(kRsDeferredSlots - 1);
+    D.out[(sl * 3 + 0) * 64 + owner] = r.t;
+    D.out[(sl * 3 + 1) * 64 + owner] = r.u;
+    D.out[(sl * 3 + 2) * 64 + owner] = r.v;
+    D.flag[sl * 64 + owner] = (uint8_t)((r.ok ? 1u : 0u) | (A.amb ? 2u : 0u));
+  }
+}
+
+// A lane's range test of formula F on image K of its (backwards) point: exactly the test the
+// formula starts with, on the same expression.
+template <int F>
+__device__ __forceinline__ bool pp_deferred_wanted(PpRsState& S, const PpRsInput& in, bool back, int K) {
+  const double bx = back ? in.xb : in.x, by = back ? in.yb : in.y;
+  const double ax = (K & 1) ? -bx : bx;
+  const double ay = (K & 2) ? -by : by;
+  const double sp = (K == 1 || K == 2) ? -in.sp : in.sp;
+  if constexpr (F == PP_F_LRL_) {
+    const double px = ax - sp, py = ay - 1.0 + in.cp;  // pp_polar_set, set 0
+    return S.A.le(sqrt(px * px + py * py), 4.);
+  } else if constexpr (F == PP_F_LRLRN_) {
+    const double px = ax + sp, py = ay - 1.0 - in.cp;  // set 1
+    return S.A.le(0.25 * (2.0 + sqrt(px * px + py * py)), 1.0);
+  } else {
+    const double xi = ax + sp, eta = ay - 1.0 - in.cp;
+    const double rho = (20. - xi * xi - eta * eta) / 16.0;
+    return S.A.le(0.0, rho) & S.A.le(rho, 1.0);
+  }
+}
+
+// One batch: the NC candidates of formula F (the four images; lrl: forward, then backwards),
+// tested, queued, evaluated by the wave and offered in generation order to the word set of their
+// letters (images 0, 1: wa, images 2, 3, the reflected word: wb).  Every lane of the wave must come
+// here together.
+template <int F, int J0, int NC, int N, class Sink>
+__device__ __forceinline__ void pp_deferred_batch(PpRsState& S, const PpRsInput& in, const PpRsDeferred& D,
+                                                  PpWordSet<N>& wa, PpWordSet<N>& wb, uint32_t lane,
+                                                  uint32_t word_k0, Sink& sink) {
+  uint32_t count = 0, mine = 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = J0; j < J0 + NC; ++j) {
+    const bool need = pp_deferred_wanted<F>(S, in, F == PP_F_LRL_ && j >= 4, j & 3);
+    const unsigned long long m = __ballot(need);
+    if (need) {
+      D.queue[count + (uint32_t)__popcll(m & below)] = (uint16_t)(lane | ((uint32_t)j << 6));
+      mine |= 1u << j;
+    }
+    count += (uint32_t)__popcll(m);
+  }
+  if (count == 0) return;  // uniform over the wave
+  pp_wave_sync();
+  pp_deferred_eval<F>(D, count, lane);
+  pp_wave_sync();
+#pragma unroll
+  for (int j = J0; j < J0 + NC; ++j) {
+    if (!((mine >> j) & 1u)) continue;
+    constexpr int kSlotMask = kRsDeferredSlots - 1;
+    const uint32_t f = D.flag[(j & kSlotMask) * 64 + lane];
+    if (f & 2u) S.A.amb = true;
+    if (!(f & 1u)) continue;
+    const double t = D.out[((j & kSlotMask) * 3 + 0) * 64 + lane], u = D.out[((j & kSlotMask) * 3 + 1) * 64 + lane],
+                 v = D.out[((j & kSlotMask) * 3 + 2) * 64 + lane];
+    const int K = j & 3;
+    double len[N];
+    int gen;
+    if constexpr (F == PP_F_LRL_) {
+      if (j < 4) { len[0] = t; len[1] = u; len[2] = v; gen = 10 + K; }   // PP_TUV
+      else { len[0] = v; len[1] = u; len[2] = t; gen = 14 + K; }         // PP_VUT, backwards
+    } else if constexpr (F == PP_F_LRLRN_) {
+      len[0] = t; len[1] = u; len[2] = -u; len[3] = v; gen = 18 + K;      // PP_T_U_NU_V
+    } else {
+      len[0] = t; len[1] = u; len[2] = u; len[3] = v; gen = 22 + K;       // PP_T_U_U_V
+    }
+    if (K & 1) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) len[i] = -len[i];
+    }
+    if (K & 2)
+      pp_set_path<N>(S, wb, len, gen, pp_word_reflect(word_k0), sink);
+    else
+      pp_set_path<N>(S, wa, len, gen, word_k0, sink);
+  }
+  pp_wave_sync();  // the areas are written again by the next batch
+}
+
+// generate_path for the 64 pairs of a wave (every lane of the wave takes part, whether its pair
+// counts or not); candidates reach the sink word by word, not in generation order.
 template <class Sink>
-__device__ __forceinline__ void pp_rs_generate_compact(const PpRsInput& in, PpRsState& S, Sink& sink) {
+__device__ __forceinline__ void pp_rs_generate_wave(const PpRsInput& in, PpRsState& S, const PpRsDeferred& D,
+                                                    uint32_t lane, Sink& sink) {
+  D.pin[0 * 64 + lane] = in.x;
+  D.pin[1 * 64 + lane] = in.y;
+  D.pin[2 * 64 + lane] = in.phi;
+  D.pin[3 * 64 + lane] = in.sp;
+  D.pin[4 * 64 + lane] = in.cp;
+  D.pin[5 * 64 + lane] = in.xb;
+  D.pin[6 * 64 + lane] = in.yb;
 #pragma clang loop unroll(disable)
   for (int h = 0; h < 2; ++h) {
+    // the four points the formulas of this h measure from, images 2h and 2h + 1 together
+    const PpPolarPair P[4] = {pp_polar_pair<0>(in.x, in.y, in.sp, in.cp, h), pp_polar_pair<1>(in.x, in.y, in.sp, in.cp, h),
+                              pp_polar_pair<0>(in.xb, in.yb, in.sp, in.cp, h),
+                              pp_polar_pair<1>(in.xb, in.yb, in.sp, in.cp, h)};
     {  // scs :202-211 -- generation indices 0 (image 0) and 1 (image 2)
       PpWordSet<3> a;
       pp_candidate_rt<PP_F_SLS_, false, PP_TUV, 3>(S, in, a, 2 * h, h, pp_word("SLS"), sink);
     }
     {  // csc :231-270 -- 2..5, 6..9
       PpWordSet<3> a, c;
-      pp_pair_rt<PP_F_LSL_, false, PP_TUV, 3>(S, in, a, h, 2, pp_word("LSL"), sink);
-      pp_pair_rt<PP_F_LSR_, false, PP_TUV, 3>(S, in, c, h, 6, pp_word("LSR"), sink);
-    }
-    {  // ccc :272-316 -- LRL / RLR collect four candidates each (10, 11, 14, 15 / 12, 13, 16, 17)
-      PpWordSet<3> a;
-      pp_pair_rt<PP_F_LRL_, false, PP_TUV, 3>(S, in, a, h, 10, pp_word("LRL"), sink);
-      pp_pair_rt<PP_F_LRL_, true, PP_VUT, 3>(S, in, a, h, 14, pp_word("LRL"), sink);
-    }
-    {  // cccc :366-406 -- LRLR / RLRL (18, 19, 22, 23 / 20, 21, 24, 25)
-      PpWordSet<4> a;
-      pp_pair_rt<PP_F_LRLRN_, false, PP_T_U_NU_V, 4>(S, in, a, h, 18, pp_word("LRLR"), sink);
-      pp_pair_rt<PP_F_LRLRP_, false, PP_T_U_U_V, 4>(S, in, a, h, 22, pp_word("LRLR"), sink);
+      pp_pair_rt<PP_F_LSL_, false, PP_TUV, 3>(S, in, a, h, 2, pp_word("LSL"), sink, P);
+      pp_pair_rt<PP_F_LSR_, false, PP_TUV, 3>(S, in, c, h, 6, pp_word("LSR"), sink, P);
     }
     {  // ccsc :440-524 -- 26..29, 30..33, and on the backwards point 34..37, 38..41
       PpWordSet<4> a, c;
-      pp_pair_rt<PP_F_LRSL_, false, PP_T_H_U_V, 4>(S, in, a, h, 26, pp_word("LRSL"), sink);
-      pp_pair_rt<PP_F_LRSR_, false, PP_T_H_U_V, 4>(S, in, c, h, 30, pp_word("LRSR"), sink);
+      pp_pair_rt<PP_F_LRSL_, false, PP_T_H_U_V, 4>(S, in, a, h, 26, pp_word("LRSL"), sink, P);
+      pp_pair_rt<PP_F_LRSR_, false, PP_T_H_U_V, 4>(S, in, c, h, 30, pp_word("LRSR"), sink, P);
     }
     {
       PpWordSet<4> a, c;
-      pp_pair_rt<PP_F_LRSL_, true, PP_V_U_H_T, 4>(S, in, a, h, 34, pp_word("LSRL"), sink);
-      pp_pair_rt<PP_F_LRSR_, true, PP_V_U_H_T, 4>(S, in, c, h, 38, pp_word("RSRL"), sink);
+      pp_pair_rt<PP_F_LRSL_, true, PP_V_U_H_T, 4>(S, in, a, h, 34, pp_word("LSRL"), sink, P);
+      pp_pair_rt<PP_F_LRSR_, true, PP_V_U_H_T, 4>(S, in, c, h, 38, pp_word("RSRL"), sink, P);
     }
     {  // ccscc :544-580 -- 42..45
       PpWordSet<5> a;
-      pp_pair_rt<PP_F_LRSLR_, false, PP_T_H_U_H_V, 5>(S, in, a, h, 42, pp_word("LRSLR"), sink);
+      pp_pair_rt<PP_F_LRSLR_, false, PP_T_H_U_H_V, 5>(S, in, a, h, 42, pp_word("LRSLR"), sink, P);
     }
+  }
+  {  // ccc :272-316 -- LRL / RLR collect four candidates each (10, 11, 14, 15 / 12, 13, 16, 17)
+    PpWordSet<3> a, b;
+#ifndef PP_RS_LRL_ONE
+    pp_deferred_batch<PP_F_LRL_, 0, 4, 3>(S, in, D, a, b, lane, pp_word("LRL"), sink);
+    pp_deferred_batch<PP_F_LRL_, 4, 4, 3>(S, in, D, a, b, lane, pp_word("LRL"), sink);
+#else
+    pp_deferred_batch<PP_F_LRL_, 0, 8, 3>(S, in, D, a, b, lane, pp_word("LRL"), sink);
+#endif
+  }
+  {  // cccc :366-406 -- LRLR / RLRL (18, 19, 22, 23 / 20, 21, 24, 25)
+    PpWordSet<4> a, b;
+    pp_deferred_batch<PP_F_LRLRN_, 0, 4, 4>(S, in, D, a, b, lane, pp_word("LRLR"), sink);
+    pp_deferred_batch<PP_F_LRLRP_, 0, 4, 4>(S, in, D, a, b, lane, pp_word("LRLR"), sink);
   }
 }
 

@@ -95,6 +95,14 @@ __device__ __forceinline__ double pp_pi_2_pi(double theta) {
   return theta;
 }
 
+// What two mirror images of a formula have in common once they share rho (PpPolarPair): filled in
+// by the first image that gets that far, reused by the second (same lane, same rho, so the same
+// range test let it in).
+struct PpPairMemo {
+  bool set = false;
+  double a = 0.0, b = 0.0;
+};
+
 // Base formulas; sp / cp are sin(phi) / cos(phi) of the phi passed in.
 // :213-229
 __device__ __forceinline__ PpTuv pp_f_sls(double x, double y, double phi, PpAmb& A) {
@@ -123,13 +131,20 @@ __device__ __forceinline__ PpTuv pp_f_lsl(double phi, const PpPolar& p0, PpAmb& 
   return r;
 }
 // :172-186
-__device__ __forceinline__ PpTuv pp_f_lsr(double phi, const PpPolar& p1, PpAmb& A) {
+__device__ __forceinline__ PpTuv pp_f_lsr(double phi, const PpPolar& p1, PpAmb& A, PpPairMemo* M = nullptr) {
   PpTuv r{false, 0., 0., 0.};
   double u1 = p1.rho, t1 = p1.th;
   u1 = u1 * u1;
   if (A.ge(u1, 4.)) {
-    double u = sqrt(u1 - 4.);
-    double theta = pp_atan2(2.0, u);
+    double u, theta;
+    if (M && M->set) {
+      u = M->a;
+      theta = M->b;
+    } else {
+      u = sqrt(u1 - 4.);
+      theta = pp_atan2(2.0, u);
+      if (M) *M = PpPairMemo{true, u, theta};
+    }
     double t = pp_mod2pi(t1 + theta, A);
     double v = pp_mod2pi(t - phi, A);
     if (A.ge(t, 0.) & A.ge(v, 0.0)) r = PpTuv{true, t, u, v};
@@ -204,13 +219,21 @@ __device__ __forceinline__ PpTuv pp_f_lrsr(double phi, const PpPolar& p1, PpAmb&
   return r;
 }
 // :423-438
-__device__ __forceinline__ PpTuv pp_f_lrsl(double phi, const PpPolar& p0, PpAmb& A) {
+__device__ __forceinline__ PpTuv pp_f_lrsl(double phi, const PpPolar& p0, PpAmb& A, PpPairMemo* M = nullptr) {
   PpTuv r{false, 0., 0., 0.};
   double rho = p0.rho, theta = p0.th;
   if (A.ge(rho, 2.0)) {
-    double rr = sqrt(rho * rho - 4.0);
+    double rr, alpha;
+    if (M && M->set) {
+      rr = M->a;
+      alpha = M->b;
+    } else {
+      rr = sqrt(rho * rho - 4.0);
+      alpha = pp_atan2(rr, -2.0);
+      if (M) *M = PpPairMemo{true, rr, alpha};
+    }
     double u = 2.0 - rr;
-    double t = pp_mod2pi(theta + pp_atan2(rr, -2.0), A);
+    double t = pp_mod2pi(theta + alpha, A);
     double v = pp_mod2pi(phi - 0.5 * PP_RS_PI - t, A);
     if (A.ge(t, 0.0) & A.le(u, 0.0) & A.le(v, 0.0)) r = PpTuv{true, t, u, v};
   }
@@ -319,14 +342,14 @@ __host__ __device__ constexpr int pp_formula_set() {
 
 template <int F>
 __device__ __forceinline__ PpTuv pp_eval(double x, double y, double phi, double sp, double cp, const PpPolar& pol,
-                                         PpAmb& A) {
+                                         PpAmb& A, PpPairMemo* M = nullptr) {
   if (F == PP_F_SLS_) return pp_f_sls(x, y, phi, A);
   if (F == PP_F_LSL_) return pp_f_lsl(phi, pol, A);
-  if (F == PP_F_LSR_) return pp_f_lsr(phi, pol, A);
+  if (F == PP_F_LSR_) return pp_f_lsr(phi, pol, A, M);
   if (F == PP_F_LRL_) return pp_f_lrl(phi, pol, A);
   if (F == PP_F_LRLRN_) return pp_f_lrlrn(x, y, phi, sp, cp, pol, A);
   if (F == PP_F_LRLRP_) return pp_f_lrlrp(x, y, phi, sp, cp, A);
-  if (F == PP_F_LRSL_) return pp_f_lrsl(phi, pol, A);
+  if (F == PP_F_LRSL_) return pp_f_lrsl(phi, pol, A, M);
   if (F == PP_F_LRSR_) return pp_f_lrsr(phi, pol, A);
   return pp_f_lrslr(x, y, phi, sp, cp, pol, A);
 }
@@ -641,7 +664,7 @@ __device__ __forceinline__ PpPolarPair pp_polar_pair(double bx, double by, doubl
 template <int F, bool BACK, int LAY, int N, class Sink>
 __device__ __forceinline__ void pp_candidate_rt(PpRsState& S, const PpRsInput& in, PpWordSet<N>& ws, int K,
                                                 int gen, uint32_t word_k0, Sink& sink,
-                                                const PpPolarPair* P = nullptr) {
+                                                const PpPolarPair* P = nullptr, PpPairMemo* M = nullptr) {
   const double bx = BACK ? in.xb : in.x, by = BACK ? in.yb : in.y;
   const double ax = (K & 1) ? -bx : bx;
   const double ay = (K & 2) ? -by : by;
@@ -658,7 +681,7 @@ __device__ __forceinline__ void pp_candidate_rt(PpRsState& S, const PpRsInput& i
       pol = pp_polar_set(ax, ay, sp, in.cp, SET);
     }
   }
-  PpTuv r = pp_eval<F>(ax, ay, ap, sp, in.cp, pol, S.A);
+  PpTuv r = pp_eval<F>(ax, ay, ap, sp, in.cp, pol, S.A, P ? M : nullptr);  // (the memo presumes the shared rho)
   if (!r.ok) return;
   const double H = 0.5 * PP_RS_PI;
   double len[N];
@@ -683,8 +706,10 @@ __device__ __forceinline__ void pp_pair_rt(PpRsState& S, const PpRsInput& in, Pp
                                            uint32_t word_k0, Sink& sink, const PpPolarPair* P = nullptr) {
   // unrolled: as a loop the two images keep every word set of the enclosing block in registers at
   // once (a few hundred spilled registers, 0.63 -> 0.82 ms per million pairs)
+  PpPairMemo memo;
 #pragma unroll
-  for (int f = 0; f < 2; ++f) pp_candidate_rt<F, BACK, LAY, N>(S, in, ws, 2 * h + f, gen0 + 2 * h + f, word_k0, sink, P);
+  for (int f = 0; f < 2; ++f)
+    pp_candidate_rt<F, BACK, LAY, N>(S, in, ws, 2 * h + f, gen0 + 2 * h + f, word_k0, sink, P, &memo);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -543,9 +543,18 @@ def test_batch_planned_in_parts_equals_unsplit(ctx):
         ctx.set_max_expansions(100000)
     seen = set(int(v) for v in runs[0]["status"])
     assert {A.PP_OK, A.PP_ERR_LIMIT, A.PP_ERR_DEGENERATE_RS} <= seen, seen
-    for r in runs[1:]:
-        for k in keys + ("exp",):
-            assert np.array_equal(runs[0][k], r[k], equal_nan=True), k
+    for which, r in enumerate(runs[1:], 1):
+        for k in ("exp", "status") + keys:
+            if not np.array_equal(runs[0][k], r[k], equal_nan=True):
+                a0, a1 = runs[0][k].reshape(len(starts), -1), r[k].reshape(len(starts), -1)
+                rows = np.nonzero(((a0 != a1) & ~((a0 != a0) & (a1 != a1))).any(axis=1))[0]
+                i = int(rows[0])
+                raise AssertionError(
+                    f"run {which} differs from the unsplit run in {k!r} for {len(rows)} queries, first {i}: "
+                    f"status {runs[0]['status'][i]} / {r['status'][i]}, closed {runs[0]['exp'][i]} / {r['exp'][i]}, "
+                    f"cost {runs[0]['cost'][i]} / {r['cost'][i]}, len {runs[0]['len'][i]} / {r['len'][i]}, "
+                    f"first differing closed position "
+                    f"{int(np.argmax(runs[0]['closed'][i] != r['closed'][i])) if (runs[0]['closed'][i] != r['closed'][i]).any() else None}")
     # the automatic choice split this batch (more lanes than one part has), and all of it was planned
     assert runs[1]["counters"]["lanes"] > runs[0]["counters"]["lanes"]
     assert all(r["counters"]["queries"] == len(starts) for r in runs)

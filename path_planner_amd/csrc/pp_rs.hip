@@ -80,12 +80,7 @@ k_rs_batch(uint64_t n, const double* __restrict__ sx, const double* __restrict__
   // each wave's areas for the formulas it evaluates apart (pp_rs_generate_wave)
   __shared__ __attribute__((aligned(16))) unsigned char area[2][(kRsDeferredBytes + 15) & ~(size_t)15];
   const uint32_t lane = threadIdx.x & 63u;
-  unsigned char* const mine = area[threadIdx.x >> 6];
-  PpRsDeferred D;
-  D.pin = (double*)mine;
-  D.out = D.pin + 7 * 64;
-  D.flag = (uint8_t*)(D.out + kRsDeferredSlots * 3 * 64);
-  D.queue = (uint16_t*)(D.flag + kRsDeferredSlots * 64);
+  const PpRsDeferred D = pp_deferred_areas(area[threadIdx.x >> 6]);
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   // a wave goes round as long as any of its lanes has a pair: the lanes work on one another's candidates
   for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {

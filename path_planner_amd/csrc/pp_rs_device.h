@@ -847,11 +847,17 @@ __device__ __forceinline__ void pp_deferred_batch(PpRsState& S, const PpRsInput&
   pp_wave_sync();  // the areas are written again by the next batch
 }
 
-// generate_path for the 64 pairs of a wave (every lane of the wave takes part, whether its pair
-// counts or not); candidates reach the sink word by word, not in generation order.
-template <class Sink>
-__device__ __forceinline__ void pp_rs_generate_wave(const PpRsInput& in, PpRsState& S, const PpRsDeferred& D,
-                                                    uint32_t lane, Sink& sink) {
+// The wave's areas carved out of kRsDeferredBytes of LDS (16-byte aligned).
+__device__ __forceinline__ PpRsDeferred pp_deferred_areas(unsigned char* mem) {
+  PpRsDeferred D;
+  D.pin = (double*)mem;
+  D.out = D.pin + 7 * 64;
+  D.flag = (uint8_t*)(D.out + kRsDeferredSlots * 3 * 64);
+  D.queue = (uint16_t*)(D.flag + kRsDeferredSlots * 64);
+  return D;
+}
+// The lanes' pairs, for the lanes that will work on one another's candidates.
+__device__ __forceinline__ void pp_deferred_fill(const PpRsDeferred& D, const PpRsInput& in, uint32_t lane) {
   D.pin[0 * 64 + lane] = in.x;
   D.pin[1 * 64 + lane] = in.y;
   D.pin[2 * 64 + lane] = in.phi;
@@ -859,6 +865,35 @@ __device__ __forceinline__ void pp_rs_generate_wave(const PpRsInput& in, PpRsSta
   D.pin[4 * 64 + lane] = in.cp;
   D.pin[5 * 64 + lane] = in.xb;
   D.pin[6 * 64 + lane] = in.yb;
+}
+// ccc :272-316 -- LRL / RLR collect four candidates each (10, 11, 14, 15 / 12, 13, 16, 17); after
+// pp_deferred_fill, every lane of the wave together.
+template <class Sink>
+__device__ __forceinline__ void pp_deferred_ccc(PpRsState& S, const PpRsInput& in, const PpRsDeferred& D,
+                                                uint32_t lane, Sink& sink) {
+  PpWordSet<3> a, b;
+#ifndef PP_RS_LRL_ONE
+  pp_deferred_batch<PP_F_LRL_, 0, 4, 3>(S, in, D, a, b, lane, pp_word("LRL"), sink);
+  pp_deferred_batch<PP_F_LRL_, 4, 4, 3>(S, in, D, a, b, lane, pp_word("LRL"), sink);
+#else
+  pp_deferred_batch<PP_F_LRL_, 0, 8, 3>(S, in, D, a, b, lane, pp_word("LRL"), sink);
+#endif
+}
+// cccc :366-406 -- LRLR / RLRL (18, 19, 22, 23 / 20, 21, 24, 25)
+template <class Sink>
+__device__ __forceinline__ void pp_deferred_cccc(PpRsState& S, const PpRsInput& in, const PpRsDeferred& D,
+                                                 uint32_t lane, Sink& sink) {
+  PpWordSet<4> a, b;
+  pp_deferred_batch<PP_F_LRLRN_, 0, 4, 4>(S, in, D, a, b, lane, pp_word("LRLR"), sink);
+  pp_deferred_batch<PP_F_LRLRP_, 0, 4, 4>(S, in, D, a, b, lane, pp_word("LRLR"), sink);
+}
+
+// generate_path for the 64 pairs of a wave (every lane of the wave takes part, whether its pair
+// counts or not); candidates reach the sink word by word, not in generation order.
+template <class Sink>
+__device__ __forceinline__ void pp_rs_generate_wave(const PpRsInput& in, PpRsState& S, const PpRsDeferred& D,
+                                                    uint32_t lane, Sink& sink) {
+  pp_deferred_fill(D, in, lane);
 #pragma clang loop unroll(disable)
   for (int h = 0; h < 2; ++h) {
     // the four points the formulas of this h measure from, images 2h and 2h + 1 together
@@ -889,20 +924,8 @@ __device__ __forceinline__ void pp_rs_generate_wave(const PpRsInput& in, PpRsSta
       pp_pair_rt<PP_F_LRSLR_, false, PP_T_H_U_H_V, 5>(S, in, a, h, 42, pp_word("LRSLR"), sink, P);
     }
   }
-  {  // ccc :272-316 -- LRL / RLR collect four candidates each (10, 11, 14, 15 / 12, 13, 16, 17)
-    PpWordSet<3> a, b;
-#ifndef PP_RS_LRL_ONE
-    pp_deferred_batch<PP_F_LRL_, 0, 4, 3>(S, in, D, a, b, lane, pp_word("LRL"), sink);
-    pp_deferred_batch<PP_F_LRL_, 4, 4, 3>(S, in, D, a, b, lane, pp_word("LRL"), sink);
-#else
-    pp_deferred_batch<PP_F_LRL_, 0, 8, 3>(S, in, D, a, b, lane, pp_word("LRL"), sink);
-#endif
-  }
-  {  // cccc :366-406 -- LRLR / RLRL (18, 19, 22, 23 / 20, 21, 24, 25)
-    PpWordSet<4> a, b;
-    pp_deferred_batch<PP_F_LRLRN_, 0, 4, 4>(S, in, D, a, b, lane, pp_word("LRLR"), sink);
-    pp_deferred_batch<PP_F_LRLRP_, 0, 4, 4>(S, in, D, a, b, lane, pp_word("LRLR"), sink);
-  }
+  pp_deferred_ccc(S, in, D, lane, sink);
+  pp_deferred_cccc(S, in, D, lane, sink);
 }
 
 // generate_path, :707-725: the families in the reference's order.

@@ -1085,10 +1085,12 @@ int32_t pp_rs_selected_batch(pp_ctx* ctx, uint32_t n, const double* q6 /* 6 arra
   if (tot_pts == 0) return PP_OK;
   // pass 2: the points, packed.  The words are generated again if the scratch buffer has to move.
   const size_t b_t = al256(tot_pts * 8);
-  const void* before = ctx->scratch;
+  // (the buffer's size tells whether it was replaced; its address does not, a new allocation can be
+  // handed the address that was just freed, with other contents)
+  const size_t bytes_before = ctx->scratch_bytes;
   st = pp_scratch_reserve(ctx, fixed + 4 * b_t);
   if (st != PP_OK) return st;
-  if (ctx->scratch != before) {
+  if (ctx->scratch_bytes != bytes_before) {
     carve((char*)ctx->scratch, d_q, d_c, d_p, d_sel, d_np, d_fl, d_tot, d_off);
     PP_HIP(ctx, hipMemcpyAsync(d_q, q6, (size_t)n * 48, hipMemcpyHostToDevice, s));
     PP_HIP(ctx, hipMemcpyAsync(d_sel, sel, (size_t)n * 4, hipMemcpyHostToDevice, s));

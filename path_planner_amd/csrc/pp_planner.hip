@@ -1318,7 +1318,8 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     if (ni < kRoundFusedMax) {
       pp_round_launch(ctx, map, conf, plan, (uint32_t)ni, dq, maxc, (PpShotOut*)(od + ln.r_shot),
                       (const int64_t*)(dd + r_dir), (const double*)(dd + r_steer), (const double*)(dd + r_cost),
-                      (const double*)d_mot, eo, n_upd, ln.upd, (unsigned long long*)ctx->ftab_buf);
+                      (const double*)d_mot, eo, n_upd, ln.upd, (unsigned long long*)ctx->ftab_buf,
+                      direct ? ln.done : nullptr);  // nothing follows the kernel: it carries the lane's event
     } else {
       pp_ftab_update_launch(ctx, n_upd, ln.upd, (unsigned long long*)ctx->ftab_buf, ftab_slots);
       PpRsCand* cands = (PpRsCand*)(dw + o_cand) + ln.item_base * PP_RS_MAX_PATHS;
@@ -1330,7 +1331,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     }
     PP_HIP(ctx, hipGetLastError());
     if (!direct && !out_host) PP_HIP(ctx, hipMemcpyAsync(h + r_in, dd + r_in, r_out, hipMemcpyDeviceToHost, s));
-    PP_HIP(ctx, hipEventRecord(ln.done, s));
+    if (!direct) PP_HIP(ctx, hipEventRecord(ln.done, s));  // (a direct round is one launch: see above)
     ln.in_flight = true;
     if (prof) p_dev[ln.pc] += now_ms() - p2;
     return PP_OK;

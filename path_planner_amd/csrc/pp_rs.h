@@ -50,7 +50,9 @@ struct PpFtabUpd;
 void pp_round_launch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, const PpExpandPlan& plan, uint32_t n,
                      const double* d_q, double maxc, PpShotOut* d_out, const int64_t* d_pdir,
                      const double* d_psteer, const double* d_pcost, const double* d_motion, PpExpandDev eo,
-                     uint32_t n_upd = 0, const PpFtabUpd* upd = nullptr, unsigned long long* ftab = nullptr);
+                     uint32_t n_upd = 0, const PpFtabUpd* upd = nullptr, unsigned long long* ftab = nullptr,
+                     hipEvent_t done = nullptr);
+// done: an event to record at the end of the launch (as hipEventRecord behind it would)
 int32_t pp_rs_single(pp_ctx* ctx, const double q[6], double maxc, double step_size, int only_rank,
                      int32_t* n_paths, pp_rs_word* words, uint64_t* traj_off, double* traj_x,
                      double* traj_y, double* traj_yaw, int64_t* traj_dir, uint64_t traj_cap,

@@ -492,9 +492,11 @@ struct PlanState {
   std::unique_ptr<Pool> pool;
   unsigned pool_workers = 0;
   hipEvent_t lane_done[2] = {nullptr, nullptr};  // a lane's results have reached the pinned area
+  hipStream_t lane_stream = nullptr;             // the second lane's launches (the first lane uses the context's stream)
   ~PlanState() {
     for (hipEvent_t e : lane_done)
       if (e) (void)hipEventDestroy(e);
+    if (lane_stream) (void)hipStreamDestroy(lane_stream);
   }
 };
 
@@ -751,11 +753,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
 #endif
   constexpr size_t kRoundOutHostMin = PP_ROUND_OUT_HOST_MIN;  // nodes; from this on results go straight to it
   // a large batch runs as two lanes (below), each with its own half of the staging buffers
-#ifndef PP_LANE_MERGE_WAIT
-#define PP_LANE_MERGE_WAIT 0.3
-#endif
-  constexpr size_t kTwoLanesMin = 1024, kLaneMergeBelow = 256;
-  constexpr double kLaneMergeWaitShare = PP_LANE_MERGE_WAIT;
+  constexpr size_t kTwoLanesMin = 1024;
   // a lane's staging area holds Bl nodes (below): a round with look-ahead sends up to kSpecItems
   static_assert(kSpecItems + kSpecDepth <= kTwoLanesMin / 2, "the look-ahead must fit a lane's staging area");
   const bool two_lanes = nq >= kTwoLanesMin;
@@ -1024,6 +1022,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     hipEvent_t done = nullptr;
     bool in_flight = false;
     int pc = 0;
+    hipStream_t stream = nullptr;
     size_t nl = 0, ni = 0, depth = 1;
     size_t r_shot = 0, r_valid = 0, r_rec = 0;
     // news for the tables of known cells, written by the workers as they apply a round
@@ -1034,6 +1033,28 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
   };
   const size_t nlanes = two_lanes ? 2 : 1;
   Lane lanes[2];
+  // The second lane has a stream of its own: its kernels then run beside the first lane's instead of
+  // behind them, so a lane waits one device latency for its results however many lanes are in flight.
+  // (The lanes hold different queries: they share no staging area, work array or table.)
+  if (two_lanes && !state.lane_stream)
+    PP_HIP(ctx, hipStreamCreateWithFlags(&state.lane_stream, hipStreamNonBlocking));
+  lanes[0].stream = lanes[1].stream = s;
+  if (two_lanes) {
+    lanes[1].stream = state.lane_stream;
+    PP_HIP(ctx, hipStreamSynchronize(s));  // the grids and tables queued on the context's stream are in
+  }
+  // the launch helpers use the context's stream: it is the lane's for the length of a lane's launches
+  struct StreamScope {
+    pp_ctx* c;
+    hipStream_t keep;
+    StreamScope(pp_ctx* c_, hipStream_t now) : c(c_), keep(c_->stream) { c->stream = now; }
+    ~StreamScope() { c->stream = keep; }
+  };
+  auto sync_lanes = [&]() -> hipError_t {
+    hipError_t e = hipStreamSynchronize(s);
+    if (two_lanes && e == hipSuccess) e = hipStreamSynchronize(state.lane_stream);
+    return e;
+  };
   for (size_t l = 0; l < nlanes; ++l) {
     lanes[l].io_base = l * io_lane;
     lanes[l].item_base = l * Bl;
@@ -1115,12 +1136,16 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     ln.upd_fail.store(UINT32_MAX, std::memory_order_relaxed);
     return n;
   };
-  auto send_updates = [&](Lane& ln, bool send) {
-    const uint32_t n = take_updates(ln);
-    if (n && send) pp_ftab_update_launch(ctx, n, ln.upd, (unsigned long long*)ctx->ftab_buf, ftab_slots);
-  };
   auto ftab_assign = [&](Lane& ln) -> int32_t {
     ln.unassigned = false;
+    // (runs on the context's stream with both lanes' streams idle before and after: the other lane's
+    // kernel in flight reads the tables, and this lane's next launch is on a stream of its own)
+    PP_HIP(ctx, sync_lanes());
+    struct SyncAtExit {
+      pp_ctx* c;
+      hipStream_t s;
+      ~SyncAtExit() { (void)hipStreamSynchronize(s); }
+    } sync_at_exit{ctx, s};
     if (ftab_slots == 0) {  // first time: tables for every query still alive
       size_t live = 0;
       for (size_t l = 0; l < nlanes; ++l) live += lanes[l].ids.size();
@@ -1135,7 +1160,6 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
       // tables shrink until they fit, or the batch goes on without them.
       size_t need = live * slots * 16;
       if (need > ctx->ftab_bytes) {
-        PP_HIP(ctx, hipStreamSynchronize(s));
         if (ctx->ftab_buf) PP_HIP(ctx, hipFree(ctx->ftab_buf));
         ctx->ftab_buf = nullptr;
         ctx->ftab_bytes = 0;
@@ -1227,7 +1251,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     ln.ids.resize(nl);
     ln.nl = nl;
     ln.ni = ni;
-    if (nl == 0) {  // the lane is done (a merge may still hand it the other lane's queries)
+    if (nl == 0) {  // the lane is done
       ln.emit.clear();
       ln.emit_n.clear();
       return PP_OK;
@@ -1303,7 +1327,9 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     char* const dw = d;  // the Reeds-Shepp work arrays stay in device memory
     const bool direct = ni < kRoundDirectMax;
     char* const dd = direct ? h : dw;
-    if (!direct) PP_HIP(ctx, hipMemcpyAsync(dd + ln.io_base, h + ln.io_base, r_in - ln.io_base, hipMemcpyHostToDevice, s));
+    const hipStream_t ls = ln.stream;
+    StreamScope on_lane_stream(ctx, ls);
+    if (!direct) PP_HIP(ctx, hipMemcpyAsync(dd + ln.io_base, h + ln.io_base, r_in - ln.io_base, hipMemcpyHostToDevice, ls));
     // A large round writes its results straight into the pinned area as well: full-wave stores
     // cross PCIe while the kernels run, where a copy afterwards takes as long again as the kernels
     // (the inputs stay in device memory: they are read once per primitive).
@@ -1330,14 +1356,13 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
                        (const double*)(dd + r_steer), (const double*)(dd + r_cost), (const double*)d_mot, eo);
     }
     PP_HIP(ctx, hipGetLastError());
-    if (!direct && !out_host) PP_HIP(ctx, hipMemcpyAsync(h + r_in, dd + r_in, r_out, hipMemcpyDeviceToHost, s));
-    if (!direct) PP_HIP(ctx, hipEventRecord(ln.done, s));  // (a direct round is one launch: see above)
+    if (!direct && !out_host) PP_HIP(ctx, hipMemcpyAsync(h + r_in, dd + r_in, r_out, hipMemcpyDeviceToHost, ls));
+    if (!direct) PP_HIP(ctx, hipEventRecord(ln.done, ls));  // (a direct round is one launch: see above)
     ln.in_flight = true;
     if (prof) p_dev[ln.pc] += now_ms() - p2;
     return PP_OK;
   };
 
-  double waited = 0.0;  // ms the host waited for results since the loop below last looked
   // (3) wait for the lane's results; the closed node is applied straight from the staging buffer,
   // the nodes fetched ahead of their turn go into the query's cache
   auto collect = [&](Lane& ln) -> int32_t {
@@ -1346,7 +1371,6 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     PP_HIP(ctx, hipEventSynchronize(ln.done));
     ln.in_flight = false;
     const double p3 = now_ms();
-    waited += p3 - p2;
     if (prof) p_dev[ln.pc] += p3 - p2;
     const PpShotOut* shot = (const PpShotOut*)(h + ln.r_shot);
     const uint8_t* v_valid = (const uint8_t*)(h + ln.r_valid);
@@ -1388,8 +1412,10 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
       // (the other lane's round in flight was launched on the bounded grids: whatever of it looked
       // beyond the limit carries the mark and comes back here at that lane's turn)
       const double pf = prof ? now_ms() : 0.0;
+      PP_HIP(ctx, sync_lanes());  // the other lane's kernel in flight reads the grids
       int32_t fst = pp_wavefront_multi_finish(ctx);
       if (fst != PP_OK) return fst;
+      PP_HIP(ctx, hipStreamSynchronize(s));  // complete before either lane launches again
       if (prof) fprintf(stderr, "[plan] heuristic grids completed during the search: %.1f ms\n", now_ms() - pf);
       h_bounded = false;
       eo.hobs = nullptr;
@@ -1403,7 +1429,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
 
   // leaving with an error: the other lane's round may still be running on the staging buffers
   auto drain = [&](int32_t code) {
-    (void)hipStreamSynchronize(s);
+    (void)sync_lanes();
     return code;
   };
   for (size_t l = 0; l < nlanes; ++l) {
@@ -1418,58 +1444,16 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
     st = launch(lanes[l]);
     if (st != PP_OK) return drain(st);
   }
-  bool merged = nlanes == 1;
-  // Two lanes pay off while the host is the slower side: one lane's results are applied and its
-  // next nodes chosen while the other's kernels run.  With few queries left and little to apply a
-  // round is the device's latency, and the host mostly waits for it: then one lane is better (one
-  // launch per round instead of two that take turns on the stream).  wait_sum / turn_sum is the
-  // part of the recent turns of the loop below the host spent waiting for a lane's results.
-  double wait_sum = 0.0, turn_sum = 0.0, turn_begin = now_ms();
-  // test hook: PP_PLAN_MERGE_TURN=n merges at turn n of the loop whatever the lanes hold (the
-  // closing orders must not depend on where the merge happens)
-  const char* const merge_env = getenv("PP_PLAN_MERGE_TURN");
-  const long merge_turn = merge_env ? atol(merge_env) : -1;
-  long turn = 0;
+  // Two lanes pay off while the host is the slower side -- one lane's results are applied and its
+  // next nodes chosen while the other's kernels run -- and cost nothing when the device is: on
+  // streams of their own both lanes' kernels are in flight together, so each lane still waits one
+  // device latency per round.  (On one stream the second lane's kernel ran behind the first's, and
+  // the lanes had to be merged once the host started waiting.)
   while (lanes[0].in_flight || lanes[1].in_flight) {
-    ++turn;
-    {
-      const double t = now_ms();
-      wait_sum = wait_sum * (15.0 / 16.0) + waited;
-      turn_sum = turn_sum * (15.0 / 16.0) + (t - turn_begin);
-      waited = 0.0;
-      turn_begin = t;
-    }
     for (size_t l = 0; l < nlanes; ++l) {
       Lane& ln = lanes[l];
       st = collect(ln);
       if (st != PP_OK) return drain(st);
-      const bool few = lanes[0].ids.size() + lanes[1].ids.size() < kLaneMergeBelow;
-      if (!merged && l == 0 &&
-          (merge_turn >= 0 ? turn == merge_turn : few && wait_sum > kLaneMergeWaitShare * turn_sum)) {
-        st = collect(lanes[1]);
-        if (st != PP_OK) return drain(st);
-        Lane& o = lanes[1];
-        if (o.stride > ln.stride) {  // records of one stride: spread lane 0's out, back to front
-          ln.emit.resize(ln.ids.size() * o.stride);
-          for (size_t k = ln.ids.size(); k-- > 0;)
-            for (size_t j = ln.emit_n[k]; j-- > 0;) ln.emit[k * o.stride + j] = ln.emit[k * ln.stride + j];
-          ln.stride = o.stride;
-        }
-        for (size_t k = 0; k < o.ids.size(); ++k)
-          if (o.emit[k * o.stride].alive) {
-            ln.ids.push_back(o.ids[k]);
-            ln.emit_n.push_back(o.emit_n[k]);
-            ln.emit.resize(ln.ids.size() * ln.stride);
-            for (size_t j = 0; j < o.emit_n[k]; ++j) ln.emit[(ln.ids.size() - 1) * ln.stride + j] = o.emit[k * o.stride + j];
-          }
-        o.ids.clear();
-        o.emit.clear();
-        o.emit_n.clear();
-        send_updates(o, ftab_slots != 0);  // what its last round found out
-        ln.unassigned = true;     // its queries may be without tables
-        merged = true;
-      }
-      if (merged && l == 1) continue;
       st = launch(ln);
       if (st != PP_OK) return drain(st);
     }

@@ -224,10 +224,9 @@ def test_plan_batch_many_queries_on_a_large_map_vs_oracle(ctx):
 
 
 def test_large_batch_in_two_lanes_equals_small_batches_and_oracle(ctx):
-    """From 1024 queries on a batch runs as two lanes that alternate between host and device and
-    merge into one when few queries are left.  Every query must come out as it does in batches
-    below that size (one lane), and a sample of them as the CPU oracle has it; the map is dense
-    enough for many searches to outlive the merge."""
+    """From 1024 queries on a batch runs as two lanes, on a stream each, that alternate on the host.
+    Every query must come out as it does in batches below that size (one lane), and a sample of them
+    as the CPU oracle has it; the map is dense enough for many long searches."""
     occ = W.plan_map(1024, 0.02)
     ox, oy = W.raster_to_points(occ)
     m = api.ObstacleMap(ctx, raster=occ)
@@ -244,7 +243,7 @@ def test_large_batch_in_two_lanes_equals_small_batches_and_oracle(ctx):
         big = api.plan_batch(ctx, m, CONF, starts, goals, cap=2048, closed_cap=400)
         big = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in big.items()}
         big_exp = np.array([int(s.expansions) for s in big["stats"]])
-        assert (big_exp > 40).sum() > 100, "too few long searches to exercise the merged lane"
+        assert (big_exp > 40).sum() > 100, "too few long searches"
         for lo in range(0, 1500, 500):
             part = api.plan_batch(ctx, m, CONF, starts[lo:lo + 500], goals[lo:lo + 500], cap=2048, closed_cap=400)
             sl = slice(lo, lo + 500)
@@ -407,12 +406,11 @@ def test_table_budget_does_not_change_a_batch(ctx):
             assert np.array_equal(v, r[k], equal_nan=True), k
 
 
-def test_lane_merge_point_does_not_change_a_batch(ctx):
-    """When the two lanes of a large batch merge is a matter of timing (the host merges them once it
-    mostly waits for the device).  Forced to a range of turns of the round loop -- early, with
-    hundreds of queries in each lane, and late, when each query sends several nodes per round and
-    the tables of known cells are in use -- every query comes out as in the unforced run."""
-    import os
+def test_two_lanes_with_one_emptied_early_equal_one_lane(ctx):
+    """The two lanes of a large batch run on streams of their own and share the tables of known cells
+    and the heuristic grids.  A batch dealt so that one lane (the even positions) holds only short
+    searches -- it is done long before the other, which then goes on alone, several nodes per query
+    and round, tables in use -- comes out as its halves do when planned as batches of one lane."""
     occ = W.plan_map(1024, 0.02)
     m = api.ObstacleMap(ctx, raster=occ)
     cs, cg = W.plan_queries(6000, 1024, 16, min_dist=20.0, max_dist=150.0)
@@ -421,50 +419,35 @@ def test_lane_merge_point_does_not_change_a_batch(ctx):
     inside = (cs[:, 0] > 8) & (cs[:, 0] < 1015) & (cs[:, 1] > 8) & (cs[:, 1] < 1015)
     keep = np.nonzero(inside & (fs == 0) & (fg == 0))[0][:1200]
     starts, goals = cs[keep], cg[keep]
+    keys = ("status", "len", "cost", "x", "y", "yaw", "dir", "closed")
+
+    def run(st, go):
+        r = api.plan_batch(ctx, m, CONF, st, go, cap=2048, closed_cap=1500)
+        out = {k: np.array(r[k], copy=True) for k in keys}
+        out["exp"] = np.array([int(s.expansions) for s in r["stats"]])
+        out["poses"] = np.array([int(s.poses_checked) for s in r["stats"]])
+        out["lanes"] = api.plan_batch_counters(ctx)["lanes"]
+        return out
+
     ctx.set_max_expansions(1500)
-    runs = {}
     try:
-        for turn in (None, 1, 3, 20, 70, 110, 160, 240, 400, 10 ** 6):
-            if turn is None:
-                os.environ.pop("PP_PLAN_MERGE_TURN", None)
-            else:
-                os.environ["PP_PLAN_MERGE_TURN"] = str(turn)
-            r = api.plan_batch(ctx, m, CONF, starts, goals, cap=2048, closed_cap=1500)
-            runs[turn] = {k: np.array(r[k], copy=True) for k in ("status", "len", "cost", "x", "y", "yaw", "dir", "closed")}
-            runs[turn]["exp"] = np.array([int(s.expansions) for s in r["stats"]])
-            runs[turn]["poses"] = np.array([int(s.poses_checked) for s in r["stats"]])
-            runs[turn]["rounds"] = api.plan_batch_counters(ctx)["rounds"]
-    finally:
-        os.environ.pop("PP_PLAN_MERGE_TURN", None)
-        ctx.set_max_expansions(100000)
-    ref = runs[None]
-    assert (ref["exp"] > 300).sum() >= 8, "too few long searches to outlive a late merge"
-    assert ref["rounds"] > 400, ref["rounds"]
-    for turn, r in runs.items():
+        halves = [run(starts[lo:lo + 600], goals[lo:lo + 600]) for lo in (0, 600)]
+        assert all(h["lanes"] == 1 for h in halves)
+        ref = {k: np.concatenate([h[k] for h in halves]) for k in keys + ("exp", "poses")}
+        assert (ref["exp"] > 300).sum() >= 8, "too few long searches"
+        both = run(starts, goals)
+        assert both["lanes"] == 2
         for k, v in ref.items():
-            if k != "rounds":
-                assert np.array_equal(v, r[k], equal_nan=True), (turn, k)
-    # The same queries dealt so that one lane (the even positions) holds the short searches and is
-    # long done when the merge comes: it then takes over the other lane's queries from nothing.
-    order = np.argsort(ref["exp"], kind="stable")
-    half = len(order) // 2
-    perm = np.empty(2 * half, dtype=np.int64)
-    perm[0::2], perm[1::2] = order[:half], order[len(order) - half:]
-    lane0_last = int(ref["exp"][order[half - 1]])
-    assert lane0_last < 60, lane0_last
-    ctx.set_max_expansions(1500)
-    try:
-        for turn in (None, lane0_last + 40, 300, 700):
-            if turn is None:
-                os.environ.pop("PP_PLAN_MERGE_TURN", None)
-            else:
-                os.environ["PP_PLAN_MERGE_TURN"] = str(turn)
-            r = api.plan_batch(ctx, m, CONF, starts[perm], goals[perm], cap=2048, closed_cap=1500)
-            for k in ("status", "len", "cost", "x", "y", "yaw", "dir", "closed"):
-                assert np.array_equal(ref[k][perm], r[k], equal_nan=True), (turn, k)
-            assert np.array_equal(ref["exp"][perm], [int(s.expansions) for s in r["stats"]]), turn
+            assert np.array_equal(v, both[k], equal_nan=True), k
+        order = np.argsort(ref["exp"], kind="stable")
+        half = len(order) // 2
+        perm = np.empty(2 * half, dtype=np.int64)
+        perm[0::2], perm[1::2] = order[:half], order[len(order) - half:]
+        assert int(ref["exp"][order[half - 1]]) < 60
+        dealt = run(starts[perm], goals[perm])
+        for k, v in ref.items():
+            assert np.array_equal(v[perm], dealt[k], equal_nan=True), k
     finally:
-        os.environ.pop("PP_PLAN_MERGE_TURN", None)
         ctx.set_max_expansions(100000)
 
 

@@ -14,7 +14,7 @@
 #include "pp_expand_device.h"
 
 #ifdef PP_LAB_STAMPS
-__device__ long long lab_stamp[16];
+__device__ long long lab_stamp[32];  // [0, 8): phases of workgroup 0; [16, 28): when each formula wave of k_round was done
 #define PP_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) lab_stamp[k] = wall_clock64(); } while (0)
 extern "C" int32_t pp_lab_stamps(long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(lab_stamp), sizeof(lab_stamp)) == hipSuccess ? 0 : -1;
@@ -700,6 +700,9 @@ k_round(uint32_t n, const double* __restrict__ q6 /* sx sy syaw gx gy gyaw, n ea
                                        q6[5 * (size_t)n + i], maxc);
       PpAmb A{false};
       pp_rs_eval_wave(in, (int)wave, (int)wl, A, s_raw);
+#ifdef PP_LAB_STAMPS
+      if (wl == 0 && blockIdx.x == 0) lab_stamp[16 + wave] = wall_clock64();
+#endif
       if (A.amb) atomicOr(&s_fl, 2u);
     }
     __syncthreads();

@@ -15,7 +15,8 @@ lib = ctx.lib
 lib.pp_lab_stamps.argtypes = [C.POINTER(C.c_longlong)]
 for rep in range(4):
     r = api.hybrid_astar_planning(ctx, m, conf, sx, sy, syaw, gx, gy, gyaw)
-    buf = (C.c_longlong * 16)()
+    buf = (C.c_longlong * 32)()
     lib.pp_lab_stamps(buf)
     t = np.array(buf[:8], dtype=np.int64)
     print("us since kernel start (100 MHz clock):", [(int(v - t[0])) / 100.0 for v in t[1:8]])
+    print("   formula waves 0..11 done at:", [(int(v - t[0])) / 100.0 for v in buf[16:28]])

@@ -447,7 +447,16 @@ def test_two_lanes_with_one_emptied_early_equal_one_lane(ctx):
         dealt = run(starts[perm], goals[perm])
         for k, v in ref.items():
             assert np.array_equal(v[perm], dealt[k], equal_nan=True), k
+        # heuristic grids relaxed to a low cost limit only: a lane whose search looks beyond it has
+        # the grids completed while the other lane's round is in flight on its own stream
+        for lim in (3.0, 40.0):
+            ctx.set_heuristic_limit(lim)
+            bounded = run(starts, goals)
+            assert bounded["lanes"] == 2
+            for k, v in ref.items():
+                assert np.array_equal(v, bounded[k], equal_nan=True), (lim, k)
     finally:
+        ctx.set_heuristic_limit(-1.0)
         ctx.set_max_expansions(100000)
 
 

@@ -101,6 +101,7 @@ struct pp_ctx {
   // a large pp_plan_batch runs as several parts, each on a helper context of this device (owned)
   std::vector<pp_ctx*> helpers;
   bool is_helper = false;
+  void* lent_pool = nullptr;  // while a part of a larger batch: the worker pool the parts share (pp_planner.hip)
   uint32_t batch_parts = 0;  // 0 = chosen from the batch size and host_threads (pp_ctx_set_batch_parts)
   // slab sessions created on this context and not yet destroyed (a list owned by pp_heuristic.hip);
   // pp_ctx_destroy releases their device memory and leaves the handles inert

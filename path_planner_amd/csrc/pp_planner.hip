@@ -24,6 +24,7 @@
 
 #include "pp_expand_device.h"
 #include "pp_internal.h"
+#include "pp_pool.h"
 #include "pp_rs.h"
 
 extern "C" int32_t pp_wavefront_dev(pp_ctx*, uint64_t, uint64_t, const uint8_t*, uint64_t, uint64_t,
@@ -389,108 +390,12 @@ inline uint64_t calc_index(uint64_t xind, uint64_t yind, int64_t yawind, const p
   return (uint64_t)(yawind - P.minyaw) * P.xw * P.yw + (yind - P.miny) * P.xw + (xind - P.minx);
 }
 
-// Fork-join pool for the per-query host work of a round: run(n, fn) calls fn(i) for i in [0, n) on
-// the workers and the caller.  A round is short and the next one follows
-// within a few hundred microseconds, so a worker spins on the job counter for a while before it
-// goes to sleep on the condition variable (waking a sleeper costs more than a small round's work),
-// and the caller spins the same way for the workers to finish.
-class Pool {
- public:
-  explicit Pool(unsigned workers) {
-    for (unsigned i = 0; i < workers; ++i) th_.emplace_back([this] { loop(); });
-  }
-  ~Pool() {
-    {
-      std::lock_guard<std::mutex> l(m_);
-      stop_.store(true, std::memory_order_release);
-    }
-    cv_.notify_all();
-    for (auto& t : th_) t.join();
-  }
-  // `chunk` = items a thread takes at a time: small for items that are work, large for trivial ones;
-  // fewer than `serial_below` items run on the calling thread
-  void run(size_t n, const std::function<void(size_t)>& fn, size_t chunk = 16, size_t serial_below = 64) {
-    if (n == 0) return;
-    chunk_ = chunk;
-    if (th_.empty() || n < serial_below) {
-      for (size_t i = 0; i < n; ++i) fn(i);
-      return;
-    }
-    fn_ = &fn;
-    n_ = n;
-    next_.store(0, std::memory_order_relaxed);
-    pending_.store(th_.size(), std::memory_order_relaxed);
-    {
-      std::lock_guard<std::mutex> l(m_);  // a worker between its predicate check and its sleep holds m_
-      gen_.fetch_add(1, std::memory_order_release);
-    }
-    cv_.notify_all();
-    work();
-    if (!spin_until([this] { return pending_.load(std::memory_order_acquire) == 0; })) {
-      std::unique_lock<std::mutex> l(m_);
-      done_.wait(l, [this] { return pending_.load(std::memory_order_acquire) == 0; });
-    }
-    fn_ = nullptr;
-  }
-
- private:
-  static constexpr double kSpinMs = 0.3;
-  template <class Pred>
-  static bool spin_until(Pred&& p) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      for (int k = 0; k < 64; ++k) {
-        if (p()) return true;
-        __builtin_ia32_pause();
-      }
-      if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > kSpinMs)
-        return p();
-    }
-  }
-  void work() {
-    for (;;) {
-      const size_t c = chunk_;
-      size_t i = next_.fetch_add(c);
-      if (i >= n_) break;
-      size_t e = std::min(n_, i + c);
-      for (; i < e; ++i) (*fn_)(i);
-    }
-  }
-  void loop() {
-    uint64_t seen = 0;
-    for (;;) {
-      auto news = [&] {
-        return stop_.load(std::memory_order_acquire) || gen_.load(std::memory_order_acquire) != seen;
-      };
-      if (!spin_until(news)) {
-        std::unique_lock<std::mutex> l(m_);
-        cv_.wait(l, news);
-      }
-      if (stop_.load(std::memory_order_acquire)) return;
-      seen = gen_.load(std::memory_order_acquire);
-      work();
-      if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-        std::lock_guard<std::mutex> l(m_);
-        done_.notify_one();
-      }
-    }
-  }
-  std::vector<std::thread> th_;
-  std::mutex m_;
-  std::condition_variable cv_, done_;
-  const std::function<void(size_t)>* fn_ = nullptr;
-  size_t n_ = 0, chunk_ = 16;
-  std::atomic<size_t> next_{0};
-  std::atomic<size_t> pending_{0};
-  std::atomic<uint64_t> gen_{0};
-  std::atomic<bool> stop_{false};
-};
-
 // What a context keeps between batches: the query objects and the worker threads.
 struct PlanState {
   std::vector<Query> queries;
   std::unique_ptr<Pool> pool;
   unsigned pool_workers = 0;
+  std::unique_ptr<Pool> shared_pool;  // the workers the parts of a large batch share (pp_plan_batch)
   hipEvent_t lane_done[2] = {nullptr, nullptr};  // a lane's results have reached the pinned area
   hipStream_t lane_stream = nullptr;             // the second lane's launches (the first lane uses the context's stream)
   ~PlanState() {
@@ -499,6 +404,14 @@ struct PlanState {
     if (lane_stream) (void)hipStreamDestroy(lane_stream);
   }
 };
+
+static PlanState& plan_state_of(pp_ctx* ctx) {
+  if (!ctx->plan_state) {
+    ctx->plan_state = new PlanState();
+    ctx->plan_state_free = [](void* p) { delete (PlanState*)p; };
+  }
+  return *(PlanState*)ctx->plan_state;
+}
 
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -556,11 +469,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
   const uint64_t hxw = dims[4], hyw = dims[5], hcells = hxw * hyw;
   // the query objects live in the context between calls: thousands of small containers are
   // cheaper to clear than to free and allocate again
-  if (!ctx->plan_state) {
-    ctx->plan_state = new PlanState();
-    ctx->plan_state_free = [](void* p) { delete (PlanState*)p; };
-  }
-  PlanState& state = *(PlanState*)ctx->plan_state;
+  PlanState& state = plan_state_of(ctx);
   std::vector<Query>& Q = state.queries;
   if (Q.size() < nq) Q.resize(nq);
   std::unordered_map<uint64_t, int32_t> goal_slot;
@@ -821,12 +730,15 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
   unsigned workers = nq >= 128 ? std::min((unsigned)ctx->host_threads, hw > 1 ? hw - 1 : 0u) : 0u;
   // the worker threads are started once per context (they sleep between batches); a small batch
   // runs on the calling thread alone
+  // (the parts of a large batch share one set of workers, handed in by pp_plan_batch)
   Pool serial(0);
+  Pool* const lent = nq >= 128 ? (Pool*)ctx->lent_pool : nullptr;
+  if (lent) workers = 0;
   if (workers && (!state.pool || state.pool_workers != workers)) {
     state.pool.reset(new Pool(workers));
     state.pool_workers = workers;
   }
-  Pool& pool = workers ? *state.pool : serial;
+  Pool& pool = lent ? *lent : workers ? *state.pool : serial;
   for (hipEvent_t& e : state.lane_done)
     if (!e) PP_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   // what the device needs of the node a query wants expanded (one record per live query)
@@ -1803,8 +1715,23 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     h->is_helper = true;
     ctx->helpers.push_back(h);
   }
-  // the parts share the context's settings and its allowance of threads and memory
-  const uint32_t workers = (ctx->host_threads + 1) / parts - 1, own_workers = ctx->host_threads;
+  // The parts share the context's settings and its allowance of threads and memory.  The threads:
+  // one drives each part, the rest are one pool that serves all of them -- a part that waits for the
+  // device, or is done, leaves the workers to the others (a fixed share per part left a quarter of
+  // the cores idle in the tail of a batch).
+  const uint32_t own_workers = ctx->host_threads;
+  const unsigned hw = std::thread::hardware_concurrency();
+  const uint32_t budget = std::min<uint32_t>(ctx->host_threads + 1, hw ? hw : 1);  // threads in all
+  const uint32_t workers = budget > parts ? budget - parts : 0;
+  PlanState& own_state = plan_state_of(ctx);
+  if (workers && (!own_state.shared_pool || own_state.shared_pool->workers() != workers)) {
+    try {
+      own_state.shared_pool.reset(new Pool(workers));
+    } catch (...) {
+      own_state.shared_pool.reset();  // no threads to be had: every part works on its own thread alone
+    }
+  }
+  Pool* const lend = workers ? own_state.shared_pool.get() : nullptr;
   const size_t own_budget = ctx->ftab_budget, part_budget = own_budget / parts;
   std::vector<pp_ctx*> cs{ctx};
   for (uint32_t k = 1; k < parts; ++k) cs.push_back(ctx->helpers[k - 1]);
@@ -1814,10 +1741,12 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
     c->heuristic_pass_blocks = ctx->heuristic_pass_blocks;
     c->wave_band = ctx->wave_band;
     c->ftab_budget = part_budget;
-    c->host_threads = workers;
+    c->host_threads = 0;
+    c->lent_pool = lend;
   }
   std::vector<const pp_map*> ms(parts, map);
   st = plan_batch_dealt(cs.data(), ms.data(), parts, conf, nq, starts, goals, out, stats, status, true);
+  for (pp_ctx* c : cs) c->lent_pool = nullptr;
   ctx->host_threads = own_workers;
   ctx->ftab_budget = own_budget;
   // the batch's counters: what bounds its time is the part with the most rounds

@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--contexts", type=int, default=0,
                     help="queries workload: contexts (stream + host threads each) per GPU that share a rank's "
                          "queries through pp_plan_batch_multi, so that the latency-bound rounds of one overlap the "
-                         "others' (default 1: plain pp_plan_batch, which plans a batch of this size in four parts by itself)")
+                         "others' (default 1: plain pp_plan_batch, which plans a batch of this size in six parts by itself)")
     ap.add_argument("--batch-parts", type=int, default=0,
                     help="queries workload: pp_ctx_set_batch_parts (0 = the library's choice, 1 = never split)")
     ap.add_argument("--weak", action="store_true",

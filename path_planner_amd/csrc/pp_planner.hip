@@ -1688,13 +1688,18 @@ static int32_t plan_batch_dealt(pp_ctx* const* ctxs, const pp_map* const* maps, 
 // host side of a round has stretches only the calling thread works on, and the tables of
 // thousands of queries do not fit the host's caches; parts run those stretches side by side on
 // smaller working sets (4096 queries as four parts: 23.6 -> 20.5 ms, the search-heavy variant
-// 0.67 -> 0.55 s).  Which part a query is planned in changes nothing about its result.
+// 0.67 -> 0.55 s; since the parts share their worker threads, six).  Which part a query is planned
+// in changes nothing about its result.
 constexpr uint64_t kSplitMinQueries = 2048;
 static uint32_t batch_parts(const pp_ctx* ctx, uint64_t nq) {
   if (ctx->is_helper) return 1;
   if (ctx->batch_parts) return (uint32_t)std::min<uint64_t>(ctx->batch_parts, std::max<uint64_t>(1, nq));
   if (nq < kSplitMinQueries || ctx->host_threads < 3) return 1;
-  return std::min<uint32_t>(4, (ctx->host_threads + 1) / 2);
+  // parts of about 700 queries, six at most (they share the workers, so a part costs one driving
+  // thread): 4096 queries in six parts against four -- the light benchmark batch 16.1-16.4 ms against
+  // 19.0-19.5, the search-heavy one 268-271 against 277-285; eight parts are slower again
+  const uint64_t by_size = (nq + 767) / 768;
+  return (uint32_t)std::min<uint64_t>({6, (ctx->host_threads + 1) / 2, by_size});
 }
 
 extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config* conf, uint64_t nq,

@@ -10,7 +10,7 @@ declare -A ARGS=(
   [collision]="--workload collision --no-extra"
   [rs]="--workload rs --steps 10 --warmup 2"
   [wavefront]="--workload wavefront --steps 2 --warmup 1"
-  [queries]="--workload queries --steps 2 --warmup 1"
+  [queries]="--workload queries --steps 6 --warmup 2"
   [queries_heavy]="--workload queries --heavy --steps 2 --warmup 1"
   [expand]="--workload expand --steps 10 --warmup 2"
   [analytic]="--workload analytic --steps 5 --warmup 1"

@@ -890,7 +890,7 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
   // pushed meanwhile, found by walking the heap down from its root (the best entry not yet taken is
   // always a child of one that was).
   auto speculate = [&](Query& q, size_t depth) {
-    size_t frontier[132], nf = 0;
+    size_t frontier[3 * PP_SPEC_WALK * kSpecDepth + 8], nf = 0;  // a step takes one entry off and adds up to four
     if (q.heap.size()) frontier[nf++] = 0;
     // (a walk of three times the nodes a query may send: whatever lies deeper is several rounds away,
     // and a walk over entries that are all fetched already is the most expensive kind)

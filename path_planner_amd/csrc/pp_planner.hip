@@ -1280,7 +1280,16 @@ static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* 
   auto collect = [&](Lane& ln) -> int32_t {
     if (!ln.in_flight) return PP_OK;
     const double p2 = now_ms();
-    PP_HIP(ctx, hipEventSynchronize(ln.done));
+    if (lent) {
+      // the thread that drives a part does not sit out its wait for the device: meanwhile it takes
+      // items of the other parts' jobs, a chunk at a time
+      hipError_t qe;
+      while ((qe = hipEventQuery(ln.done)) == hipErrorNotReady)
+        if (!lent->help_once()) PP_POOL_PAUSE();
+      PP_HIP(ctx, qe);
+    } else {
+      PP_HIP(ctx, hipEventSynchronize(ln.done));
+    }
     ln.in_flight = false;
     const double p3 = now_ms();
     if (prof) p_dev[ln.pc] += p3 - p2;

@@ -89,6 +89,14 @@ class Pool {
     job->busy.store(false, std::memory_order_release);
   }
 
+  // For a thread that is waiting for something else (a caller between its own jobs): runs one
+  // chunk of whichever job has items left; false if there was nothing to do.
+  bool help_once() {
+    for (Job& j : jobs_)
+      if (work(j, true)) return true;
+    return false;
+  }
+
  private:
   static constexpr double kSpinMs = 0.3;
   static constexpr uint64_t kClosed = 0xFFFFFFFFull;  // in the low half of a job's state: no job here
@@ -104,8 +112,8 @@ class Pool {
     std::atomic<bool> busy{false};
   };
 
-  // Takes items of `job` until none is left; true if it ran any.
-  bool work(Job& job) {
+  // Takes items of `job` until none is left (or one chunk only); true if it ran any.
+  bool work(Job& job, bool one_chunk = false) {
     bool any = false;
     uint64_t s = job.state.load(std::memory_order_acquire);
     for (;;) {
@@ -123,6 +131,7 @@ class Pool {
       for (size_t i = (size_t)next; i < (size_t)end; ++i) (*fn)(i);
       job.done.fetch_add((uint32_t)(end - next), std::memory_order_release);
       any = true;
+      if (one_chunk) return true;
       s = job.state.load(std::memory_order_acquire);
     }
   }

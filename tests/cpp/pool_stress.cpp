@@ -39,6 +39,8 @@ int main(int argc, char** argv) {
           if (hits[i] != 1) ++bad;
         ++jobs;
         items += (long)n;
+        if (rng() % 4 == 0)  // a caller between its own jobs lends a hand, as a part's thread does while it waits for the device
+          for (int k = 0; k < 8; ++k) pool.help_once();
         if (rng() % 16 == 0) std::this_thread::sleep_for(std::chrono::microseconds(rng() % 700));  // lets workers fall asleep
       }
     };

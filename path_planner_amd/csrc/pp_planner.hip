@@ -396,6 +396,7 @@ struct PlanState {
   std::unique_ptr<Pool> pool;
   unsigned pool_workers = 0;
   std::unique_ptr<Pool> shared_pool;  // the workers the parts of a large batch share (pp_plan_batch)
+  unsigned shared_pool_asked = 0;     // the size it was created for (it may have got fewer threads)
   hipEvent_t lane_done[2] = {nullptr, nullptr};  // a lane's results have reached the pinned area
   hipStream_t lane_stream = nullptr;             // the second lane's launches (the first lane uses the context's stream)
   ~PlanState() {
@@ -1738,9 +1739,10 @@ extern "C" int32_t pp_plan_batch(pp_ctx* ctx, const pp_map* map, const pp_config
   const uint32_t budget = std::min<uint32_t>(ctx->host_threads + 1, hw ? hw : 1);  // threads in all
   const uint32_t workers = budget > parts ? budget - parts : 0;
   PlanState& own_state = plan_state_of(ctx);
-  if (workers && (!own_state.shared_pool || own_state.shared_pool->workers() != workers)) {
+  if (workers && (!own_state.shared_pool || own_state.shared_pool_asked != workers)) {
     try {
       own_state.shared_pool.reset(new Pool(workers));
+      own_state.shared_pool_asked = workers;
     } catch (...) {
       own_state.shared_pool.reset();  // no threads to be had: every part works on its own thread alone
     }

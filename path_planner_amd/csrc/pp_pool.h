@@ -32,7 +32,14 @@
 class Pool {
  public:
   explicit Pool(unsigned workers) {
-    for (unsigned i = 0; i < workers; ++i) th_.emplace_back([this] { loop(); });
+    th_.reserve(workers);
+    for (unsigned i = 0; i < workers; ++i) {
+      try {
+        th_.emplace_back([this] { loop(); });
+      } catch (...) {
+        break;  // no more threads to be had: the pool works with the ones it has
+      }
+    }
   }
   ~Pool() {
     {

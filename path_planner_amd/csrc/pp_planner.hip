@@ -439,10 +439,34 @@ double now_ms() {
 
 }  // namespace
 
-// One batch on one context: the lock-step rounds described at the top of the file.
+static int32_t plan_batch_rounds(pp_ctx* ctx, const pp_map* map, const pp_config* conf, uint64_t nq,
+                                 const double* starts, const double* goals, pp_path* out,
+                                 pp_plan_stats* stats, int32_t* status);
+
+// One batch on one context.  Nothing may unwind through the C boundary or out of a part's thread:
+// an exception from the host side of the rounds (in practice: no memory for a query's containers)
+// ends the batch with PP_ERR_UNSUPPORTED once the device has finished what was in flight.
 static int32_t plan_batch_core(pp_ctx* ctx, const pp_map* map, const pp_config* conf, uint64_t nq,
                                const double* starts, const double* goals, pp_path* out,
                                pp_plan_stats* stats, int32_t* status) {
+  try {
+    return plan_batch_rounds(ctx, map, conf, nq, starts, goals, out, stats, status);
+  } catch (...) {
+    if (ctx) {
+      (void)hipSetDevice(ctx->device);
+      (void)hipDeviceSynchronize();  // kernels of either lane may still be using the staging buffers
+      // the query objects may be half-built: the next batch starts from new ones (the rest of the
+      // state stays -- the other parts of a batch may be using the worker pool it holds)
+      if (ctx->plan_state) ((PlanState*)ctx->plan_state)->queries.clear();
+    }
+    return PP_ERR_UNSUPPORTED;
+  }
+}
+
+// The lock-step rounds described at the top of the file.
+static int32_t plan_batch_rounds(pp_ctx* ctx, const pp_map* map, const pp_config* conf, uint64_t nq,
+                                 const double* starts, const double* goals, pp_path* out,
+                                 pp_plan_stats* stats, int32_t* status) {
   const double t_entry = now_ms();
   if (!ctx || !map || !conf || (nq && (!starts || !goals || !out))) return PP_ERR_INVALID;
   if (map->ox.empty()) return PP_ERR_EMPTY_MAP;

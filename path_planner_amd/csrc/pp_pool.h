@@ -1,7 +1,8 @@
 // pp_pool.h -- fork-join pool for the per-query host work of the planner's rounds (host code only).
 //
 // run(n, fn) calls fn(i) for every i in [0, n) on the workers and on the calling thread and returns
-// when all of them are done.  Several threads may call run() on one pool at the same time (the
+// when all of them are done; if fn threw for some item, run() throws std::runtime_error then (the
+// other items still ran).  Several threads may call run() on one pool at the same time (the
 // parts of a large batch, each driven by a thread of its own, share the workers): a worker takes
 // items from whichever job has some left, so a part whose rounds are short, or that waits for the
 // device, leaves its share of the workers to the others.
@@ -20,6 +21,7 @@
 #include <cstdint>
 #include <functional>
 #include <mutex>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -68,13 +70,22 @@ class Pool {
       }
     }
     if (!job) {  // nothing to share the work with, or more callers at once than the pool has job slots
-      for (size_t i = 0; i < n; ++i) fn(i);
+      bool threw = false;
+      for (size_t i = 0; i < n; ++i) {
+        try {
+          fn(i);
+        } catch (...) {
+          threw = true;
+        }
+      }
+      if (threw) throw std::runtime_error("a pool item threw");
       return;
     }
     job->fn.store(&fn, std::memory_order_relaxed);
     job->n.store((uint32_t)n, std::memory_order_relaxed);
     job->chunk.store((uint32_t)(chunk ? chunk : 1), std::memory_order_relaxed);
     job->done.store(0, std::memory_order_relaxed);
+    job->threw.store(false, std::memory_order_relaxed);
     const uint64_t gen = (job->state.load(std::memory_order_relaxed) >> 32) + 1;
     job->state.store(gen << 32, std::memory_order_release);  // open: item 0 is next
     // (the epoch and the sleeper count are each written by one side and read by the other: both
@@ -92,8 +103,10 @@ class Pool {
       else
         std::this_thread::yield();
     }
+    const bool threw = job->threw.load(std::memory_order_relaxed);  // (ordered by the acquire on done)
     job->state.store((gen << 32) | kClosed, std::memory_order_release);
     job->busy.store(false, std::memory_order_release);
+    if (threw) throw std::runtime_error("a pool item threw");
   }
 
   // For a thread that is waiting for something else (a caller between its own jobs): runs one
@@ -116,6 +129,7 @@ class Pool {
     std::atomic<const std::function<void(size_t)>*> fn{nullptr};
     std::atomic<uint32_t> n{0}, chunk{1};
     std::atomic<uint32_t> done{0};
+    std::atomic<bool> threw{false};  // some item's fn left by an exception (it counts as done)
     std::atomic<bool> busy{false};
   };
 
@@ -135,7 +149,13 @@ class Pool {
         continue;  // s holds what is there now
       // the claim went through on the state the fields were read under: they belong to this job,
       // and the job cannot end before these items are counted
-      for (size_t i = (size_t)next; i < (size_t)end; ++i) (*fn)(i);
+      for (size_t i = (size_t)next; i < (size_t)end; ++i) {
+        try {  // a worker thread has nowhere to unwind to, and the caller waits for the count
+          (*fn)(i);
+        } catch (...) {
+          job.threw.store(true, std::memory_order_relaxed);
+        }
+      }
       job.done.fetch_add((uint32_t)(end - next), std::memory_order_release);
       any = true;
       if (one_chunk) return true;

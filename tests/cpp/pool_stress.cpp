@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -39,6 +40,19 @@ int main(int argc, char** argv) {
           if (hits[i] != 1) ++bad;
         ++jobs;
         items += (long)n;
+        if (rng() % 64 == 0 && n > 3) {  // an item that throws: every other item still runs, run() reports it
+          std::atomic<long> ran{0};
+          bool reported = false;
+          try {
+            pool.run(n, [&](size_t i) {
+              if (i == n / 2) throw 1;
+              ++ran;
+            }, chunk, serial_below);
+          } catch (const std::runtime_error&) {
+            reported = true;
+          }
+          if (!reported || ran.load() != (long)n - 1) ++bad;
+        }
         if (rng() % 4 == 0)  // a caller between its own jobs lends a hand, as a part's thread does while it waits for the device
           for (int k = 0; k < 8; ++k) pool.help_once();
         if (rng() % 16 == 0) std::this_thread::sleep_for(std::chrono::microseconds(rng() % 700));  // lets workers fall asleep
